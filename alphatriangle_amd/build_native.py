@@ -1,0 +1,136 @@
+"""In-tree builder of the two native libraries.
+
+* ``_atri_host``  - host C++ runtime (pybind11, g++): game engine, features,
+  host tree search, sum tree, metric ring.
+* ``libatri_hip`` - HIP/CDNA4 kernels for gfx950 (hipcc): batched game + tree
+  engine, inference network, replay and learner kernels.  Exposed with a C ABI
+  and loaded through ctypes after ``import torch`` so that it binds to the same
+  HIP runtime as PyTorch.
+
+Both are written next to this file so that they travel with the source tree.
+Run ``python -m alphatriangle_amd.build_native`` (``--host`` / ``--hip`` to pick one).
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+HOST_SO = PKG_DIR / ("_atri_host" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+HIP_SO = PKG_DIR / "libatri_hip.so"
+
+HIP_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-shared",
+    "-Xclang",
+    "-target-feature",
+    "-Xclang",
+    "-packed-fp32-ops",
+    "-Wno-unused-command-line-argument",
+    "-Wno-unknown-warning-option",
+]
+
+
+def _newer(target: Path, sources: list[Path]) -> bool:
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(s.stat().st_mtime <= t for s in sources)
+
+
+def host_sources() -> list[Path]:
+    return sorted((CSRC / "host").glob("*.cpp"))
+
+
+def hip_sources() -> list[Path]:
+    return sorted((CSRC / "hip").glob("*.hip"))
+
+
+def _all_headers() -> list[Path]:
+    return sorted(CSRC.rglob("*.h")) + sorted(CSRC.rglob("*.hpp"))
+
+
+def build_host(force: bool = False, verbose: bool = True) -> Path:
+    import pybind11
+
+    srcs = host_sources()
+    deps = srcs + _all_headers() + [Path(__file__)]
+    if not force and _newer(HOST_SO, deps):
+        return HOST_SO
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [
+        cxx,
+        "-O2",
+        "-std=c++17",
+        "-fPIC",
+        "-shared",
+        "-ffp-contract=off",
+        "-fvisibility=hidden",
+        "-Wall",
+        "-Wno-unused-function",
+        f"-I{pybind11.get_include()}",
+        f"-I{sysconfig.get_paths()['include']}",
+        *[str(s) for s in srcs],
+        "-o",
+        str(HOST_SO),
+    ]
+    if verbose:
+        print("[build_native] host:", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOST_SO
+
+
+def build_hip(force: bool = False, verbose: bool = True) -> Path:
+    srcs = hip_sources()
+    if not srcs:
+        raise RuntimeError("no HIP sources found")
+    deps = srcs + _all_headers() + [Path(__file__)]
+    if not force and _newer(HIP_SO, deps):
+        return HIP_SO
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    objs = []
+    obj_dir = PKG_DIR / "build" / "hip"
+    obj_dir.mkdir(parents=True, exist_ok=True)
+    procs = []
+    for s in srcs:
+        o = obj_dir / (s.stem + ".o")
+        objs.append(o)
+        if not force and _newer(o, [s] + _all_headers() + [Path(__file__)]):
+            continue
+        cmd = [hipcc, *[f for f in HIP_FLAGS if f != "-shared"], "-c", str(s), "-o", str(o)]
+        if verbose:
+            print("[build_native] hip:", " ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(o) for o in objs], "-o", str(HIP_SO)]
+    if verbose:
+        print("[build_native] link:", " ".join(link), flush=True)
+    subprocess.check_call(link)
+    return HIP_SO
+
+
+def build_all(force: bool = False, verbose: bool = True) -> None:
+    build_host(force, verbose)
+    build_hip(force, verbose)
+
+
+if __name__ == "__main__":
+    args = set(sys.argv[1:])
+    force = "--force" in args
+    if "--host" in args:
+        build_host(force)
+    elif "--hip" in args:
+        build_hip(force)
+    else:
+        build_all(force)

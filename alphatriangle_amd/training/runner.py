@@ -1,0 +1,146 @@
+"""Headless training entry point (parity: alphatriangle/training/runner.py:28-319)."""
+
+from __future__ import annotations
+
+import logging
+import time
+from typing import Any
+
+from ..config import AlphaTriangleMCTSConfig, EnvConfig, ModelConfig, SystemConfig, TrainConfig
+from ..logging_config import setup_logging
+from ..stats import RawMetricEvent, TrieyeConfig
+from .components import TrainingComponents
+from .logging_utils import log_configs_to_mlflow
+from .loop import TrainingLoop
+from .setup import count_parameters, setup_training_components
+
+logger = logging.getLogger(__name__)
+
+
+def _load_and_apply_initial_state(components: TrainingComponents) -> TrainingLoop:
+    """Load checkpoint / buffer through the stats actor and apply them to the components."""
+    loaded = components.trieye_actor.load_initial_state()
+    loop = TrainingLoop(components)
+    ckpt = loaded.checkpoint_data
+    if ckpt is not None:
+        logger.info("Applying loaded checkpoint data (Run: %s, Step: %d)", ckpt.run_name, ckpt.global_step)
+        if ckpt.model_state_dict:
+            components.nn.set_weights(ckpt.model_state_dict)
+        if ckpt.optimizer_state_dict:
+            try:
+                components.trainer.load_optimizer_state(ckpt.optimizer_state_dict)
+                logger.info("Optimizer state loaded and moved to device.")
+            except Exception as exc:
+                logger.error("Could not load optimizer state: %s. Optimizer might reset.", exc)
+        loop.set_initial_state(ckpt.global_step, ckpt.episodes_played, ckpt.total_simulations_run)
+        if components.gpu_actor is not None and ckpt.actor_state:
+            components.gpu_actor.load_state(ckpt.actor_state)
+    else:
+        logger.info("No checkpoint data loaded. Starting fresh.")
+        loop.set_initial_state(0, 0, 0)
+    buf = loaded.buffer_data
+    if buf is not None and buf.buffer_list:
+        logger.info("Rebuilding replay buffer from %d saved experiences (priorities restart at max).", len(buf.buffer_list))
+        components.buffer.load_list(buf.buffer_list)
+        logger.info("Buffer size after rebuild: %d", len(components.buffer))
+    else:
+        logger.info("No buffer data loaded.")
+    components.nn.model.train()
+    return loop
+
+
+def _save_final_state(loop: TrainingLoop) -> None:
+    actor = loop.trieye_actor
+    if not actor:
+        logger.warning("Cannot save final state: stats actor not available.")
+        return
+    comps = loop.components
+    logger.info("Saving final training state...")
+    try:
+        save_buffer = loop.trieye_config.persistence.SAVE_BUFFER
+        buffer_data = loop.serializer.prepare_buffer_data(comps.buffer) if save_buffer else None
+        actor.save_training_state(
+            nn_state_dict=comps.nn.get_weights(),
+            optimizer_state_dict=loop.serializer.prepare_optimizer_state(comps.trainer.optimizer.state_dict()),
+            buffer_content=buffer_data.buffer_list if buffer_data else [],
+            global_step=loop.global_step,
+            episodes_played=loop.episodes_played,
+            total_simulations_run=loop.total_simulations_run,
+            is_best=False,
+            save_buffer=bool(save_buffer and buffer_data is not None),
+            model_config_dict=comps.model_config.model_dump(),
+            env_config_dict=comps.env_config.model_dump(),
+            actor_state=comps.gpu_actor.state_dict() if comps.gpu_actor is not None else None,
+        )
+        actor.wait_for_saves(timeout=120.0)
+    except Exception as exc:
+        logger.error("Failed to save final training state: %s", exc, exc_info=True)
+
+
+def run_training(
+    log_level_str: str,
+    train_config_override: TrainConfig,
+    trieye_config_override: TrieyeConfig,
+    profile: bool,
+    model_config_override: ModelConfig | None = None,
+    mcts_config_override: AlphaTriangleMCTSConfig | None = None,
+    env_config_override: EnvConfig | None = None,
+    system_config_override: SystemConfig | None = None,
+    dist_context: Any = None,
+) -> int:
+    """Run the pipeline; exit code 0 = completed or stopped cleanly, 1 = failed."""
+    loop: TrainingLoop | None = None
+    components: TrainingComponents | None = None
+    exit_code = 1
+    actor = None
+    setup_logging(log_level_str)
+    try:
+        components, _ = setup_training_components(
+            train_config_override,
+            trieye_config_override,
+            profile,
+            model_config_override=model_config_override,
+            mcts_config_override=mcts_config_override,
+            env_config_override=env_config_override,
+            system_config_override=system_config_override,
+            dist_context=dist_context,
+        )
+        if not components:
+            raise RuntimeError("Failed to initialize training components.")
+        actor = components.trieye_actor
+        log_configs_to_mlflow(components)
+        total, trainable = count_parameters(components.nn.model)
+        logger.info("Model Parameters: Total=%s, Trainable=%s", f"{total:,}", f"{trainable:,}")
+        actor.log_params({"model_total_params": total, "model_trainable_params": trainable})
+
+        loop = _load_and_apply_initial_state(components)
+        loop.initialize_workers()
+        loop.run()
+        if loop.training_complete:
+            exit_code = 0
+        elif loop.training_exception:
+            exit_code = 1
+        else:
+            exit_code = 0  # stopped early without an error
+    except Exception as exc:
+        logger.critical("An unhandled error occurred during training setup or execution: %s", exc, exc_info=True)
+        if actor is not None:
+            step = loop.global_step if loop else 0
+            for name, value in (("training_status_code", -1.0), ("error_message_flag", 1.0)):
+                try:
+                    actor.log_event(RawMetricEvent(name=name, value=value, global_step=step, timestamp=time.time()))
+                except Exception:  # pragma: no cover
+                    pass
+        exit_code = 1
+    finally:
+        if loop is not None:
+            _save_final_state(loop)
+            loop.cleanup_actors()
+        if actor is not None:
+            try:
+                actor.force_process_and_log(loop.global_step if loop else 0)
+                actor.shutdown(timeout=15.0)
+            except Exception as exc:
+                logger.error("Error shutting down the stats actor: %s", exc)
+        logger.info("Training run finished with exit code %d.", exit_code)
+    return exit_code

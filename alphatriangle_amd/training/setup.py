@@ -1,0 +1,139 @@
+"""Builds every training component (parity: alphatriangle/training/setup.py:29-246).
+
+Ray start-up is replaced by: picking the self-play engine (HBM-resident GPU actor
+on an MI355X, CPU thread workers otherwise), clamping the CPU worker count to the
+detected cores minus two, and creating the in-process stats actor.
+"""
+
+from __future__ import annotations
+
+import logging
+import os
+from typing import Any
+
+import torch
+
+from ..config import (
+    APP_NAME,
+    AlphaTriangleMCTSConfig,
+    EnvConfig,
+    ModelConfig,
+    SystemConfig,
+    TrainConfig,
+    print_config_info_and_validate,
+)
+from ..models.network import NeuralNetwork
+from ..rl.core.buffer import ExperienceBuffer
+from ..rl.core.trainer import Trainer
+from ..stats import Serializer, StatsActor, TrieyeConfig
+from ..utils.helpers import get_device, set_random_seeds
+from .components import TrainingComponents
+
+logger = logging.getLogger(__name__)
+
+
+def count_parameters(model: torch.nn.Module) -> tuple[int, int]:
+    total = sum(p.numel() for p in model.parameters())
+    trainable = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    return total, trainable
+
+
+def _clamp_workers(requested: int) -> int:
+    cores = os.cpu_count() or 1
+    usable = max(1, cores - 2)
+    actual = max(1, min(requested, usable))
+    if actual != requested:
+        logger.info("Requested %d workers, %d cores detected -> using %d.", requested, cores, actual)
+    return actual
+
+
+def setup_training_components(
+    train_config_override: TrainConfig,
+    trieye_config_override: TrieyeConfig,
+    profile: bool,
+    model_config_override: ModelConfig | None = None,
+    mcts_config_override: AlphaTriangleMCTSConfig | None = None,
+    env_config_override: EnvConfig | None = None,
+    system_config_override: SystemConfig | None = None,
+    dist_context: Any = None,
+) -> tuple[TrainingComponents | None, bool]:
+    """Returns ``(components, runtime_started)``; ``(None, started)`` on failure."""
+    started = False
+    stats_actor: StatsActor | None = None
+    try:
+        train_config = train_config_override
+        trieye_config = trieye_config_override
+        env_config = env_config_override or EnvConfig()
+        model_config = model_config_override or ModelConfig()
+        mcts_config = mcts_config_override or AlphaTriangleMCTSConfig()
+        system_config = system_config_override or SystemConfig()
+
+        train_config.NUM_SELF_PLAY_WORKERS = _clamp_workers(train_config.NUM_SELF_PLAY_WORKERS)
+        train_config.PROFILE_WORKERS = profile
+        print_config_info_and_validate(mcts_config, system_config)
+
+        set_random_seeds(train_config.RANDOM_SEED)
+        device = get_device(train_config.DEVICE)
+        worker_device = get_device(train_config.WORKER_DEVICE)
+        logger.info("Determined Training Device: %s", device)
+        logger.info("Determined Worker Device: %s", worker_device)
+
+        stats_actor = StatsActor(trieye_config, name=f"trieye_actor_{trieye_config.run_name}")
+        started = True
+        stats_actor.attach_log_file()
+        logger.info("Stats actor ready (run id %s).", stats_actor.get_mlflow_run_id())
+
+        serializer = Serializer()
+        neural_net = NeuralNetwork(model_config, env_config, train_config, device)
+
+        use_gpu_engine = system_config.ENGINE == "gpu" or (system_config.ENGINE == "auto" and device.type == "cuda")
+        gpu_actor = None
+        buffer: Any
+        if use_gpu_engine:
+            if device.type != "cuda":
+                raise RuntimeError("SystemConfig.ENGINE='gpu' requires a GPU device")
+            from ..rl.core.device_buffer import DeviceReplayBuffer
+            from ..rl.self_play.gpu_actor import GpuSelfPlayActor
+
+            buffer = DeviceReplayBuffer(train_config, env_config, model_config, device, system_config)
+            gpu_actor = GpuSelfPlayActor(
+                env_config, model_config, mcts_config, train_config, system_config, neural_net, buffer, device,
+                seed=train_config.RANDOM_SEED + (dist_context.rank if dist_context else 0) * 1_000_003,
+            )
+        else:
+            buffer = ExperienceBuffer(train_config)
+
+        grad_sync = dist_context.grad_sync if dist_context is not None and dist_context.world_size > 1 else None
+        trainer = Trainer(
+            neural_net,
+            train_config,
+            env_config,
+            autocast_bf16=system_config.LEARNER_AUTOCAST,
+            grad_sync=grad_sync,
+            world_size=dist_context.world_size if dist_context is not None else 1,
+        )
+        components = TrainingComponents(
+            nn=neural_net,
+            buffer=buffer,
+            trainer=trainer,
+            trieye_actor=stats_actor,
+            trieye_config=trieye_config,
+            serializer=serializer,
+            train_config=train_config,
+            env_config=env_config,
+            model_config=model_config,
+            mcts_config=mcts_config,
+            profile_workers=train_config.PROFILE_WORKERS,
+            system_config=system_config,
+            gpu_actor=gpu_actor,
+            dist=dist_context,
+        )
+        return components, started
+    except Exception as exc:
+        logger.critical("Error setting up training components: %s", exc, exc_info=True)
+        if stats_actor is not None:
+            try:
+                stats_actor.shutdown(timeout=5.0)
+            except Exception:  # pragma: no cover
+                pass
+        return None, started

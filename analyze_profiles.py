@@ -1,0 +1,35 @@
+"""Inspect a cProfile ``.prof`` file written by ``train --profile`` (parity: analyze_profiles.py:41-78)."""
+
+from __future__ import annotations
+
+import pstats
+from pathlib import Path
+from typing import Annotated
+
+import typer
+
+app = typer.Typer(name="analyze-profiles", help="Analyze cProfile output files (.prof).", add_completion=False)
+
+ProfileArg = Annotated[Path, typer.Argument(help="Path to the .prof file.", exists=True, file_okay=True, dir_okay=False, readable=True, resolve_path=True)]
+LinesOpt = Annotated[int, typer.Option("--lines", "-n", help="Number of lines to show per table.")]
+
+
+@app.command()
+def analyze(profile_file: ProfileArg, num_lines: LinesOpt = 30) -> None:
+    """Print the top functions by cumulative time and by own time."""
+    print(f"\n--- Analyzing Profile: {profile_file.name} ---")
+    try:
+        stats = pstats.Stats(str(profile_file))
+    except Exception as exc:
+        print(f"Error loading profile file: {exc}")
+        raise typer.Exit(code=1) from exc
+    stats.strip_dirs()
+    print(f"\n--- Top {num_lines} by Cumulative Time ---")
+    stats.sort_stats(pstats.SortKey.CUMULATIVE).print_stats(num_lines)
+    print(f"\n--- Top {num_lines} by Total Time (tottime) ---")
+    stats.sort_stats(pstats.SortKey.TIME).print_stats(num_lines)
+    print("\n--- Analysis Complete ---")
+
+
+if __name__ == "__main__":
+    app()
