@@ -1,0 +1,301 @@
+// Learner-side fused kernels for gfx950: AlphaZero/C51 loss forward+backward, flat-buffer
+// gradient-norm clipping + optimizer update, and the HBM-resident prioritized-replay sum tree.
+//
+// Definitions being implemented:
+//   loss        alphatriangle/rl/core/trainer.py:159-271 (two-hot C51 projection, value CE,
+//               policy CE, unweighted entropy bonus, importance-weighted means)
+//   clip + opt  alphatriangle/rl/core/trainer.py:48-64,276-286 (Adam / AdamW / SGD momentum 0.9,
+//               clip_grad_norm_)
+//   PER         alphatriangle/utils/sumtree.py:25-98, alphatriangle/rl/core/buffer.py:96-195
+#include "common.hpp"
+
+using namespace atrihip;
+
+// ---------------------------------------------------------------------------
+// One wave per sample.  Writes per-sample losses and the gradients of
+//   total = wp * mean_i(w_i * pce_i) + wv * mean_i(w_i * vce_i) - we * mean_i(H_i)
+// with respect to both logit tensors.
+__global__ void az_loss_kernel(const float* __restrict__ plog, const float* __restrict__ vlog,
+                               const float* __restrict__ ptgt, const float* __restrict__ ret,
+                               const float* __restrict__ isw, float* __restrict__ pce, float* __restrict__ vce,
+                               float* __restrict__ ent, float* __restrict__ dplog, float* __restrict__ dvlog, int B,
+                               int A, int atoms, float vmin, float vmax, float wp, float wv, float we) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= B) return;
+  const float* pl = plog + (size_t)wave * A;
+  const float* pt = ptgt + (size_t)wave * A;
+  const float w = isw[wave];
+  const float invB = 1.0f / (float)B;
+  // ---- policy head
+  float m = -INFINITY;
+  for (int a = lane; a < A; a += 64) m = fmaxf(m, pl[a]);
+  m = wave_max(m);
+  float se = 0.f;
+  for (int a = lane; a < A; a += 64) se += __expf(pl[a] - m);
+  se = wave_sum(se);
+  const float lse = m + __logf(se);
+  float ce = 0.f, H = 0.f, gbar = 0.f, tsum = 0.f;
+  for (int a = lane; a < A; a += 64) {
+    float t = pt[a];
+    if (t != t) t = 0.f;  // nan_to_num on the target
+    const float logp = pl[a] - lse;
+    const float p = __expf(logp);
+    ce -= t * logp;
+    tsum += t;
+    const float lpe = __logf(p + 1e-9f);
+    H -= p * lpe;
+    gbar += p * (-lpe - p / (p + 1e-9f));
+  }
+  ce = wave_sum(ce);
+  H = wave_sum(H);
+  gbar = wave_sum(gbar);
+  tsum = wave_sum(tsum);
+  const float cp = wp * w * invB, cee = we * invB;
+  for (int a = lane; a < A; a += 64) {
+    float t = pt[a];
+    if (t != t) t = 0.f;
+    const float p = __expf(pl[a] - lse);
+    float gr = cp * (p * tsum - t);
+    if (we > 0.f) {
+      const float gk = -__logf(p + 1e-9f) - p / (p + 1e-9f);
+      gr -= cee * p * (gk - gbar);
+    }
+    dplog[(size_t)wave * A + a] = gr;
+  }
+  // ---- value head: two-hot projection of the return onto the support
+  const float* vl = vlog + (size_t)wave * atoms;
+  const float dz = (vmax - vmin) / (float)(atoms - 1);
+  const float g = fminf(fmaxf(ret[wave], vmin), vmax);
+  const float b = (g - vmin) / dz;
+  int lo = (int)floorf(b), hi = (int)ceilf(b);
+  lo = min(max(lo, 0), atoms - 1);
+  hi = min(max(hi, 0), atoms - 1);
+  const float mlo = lo == hi ? 1.0f : (float)hi - b;
+  const float mhi = lo == hi ? 0.0f : b - (float)lo;
+  float vm = -INFINITY;
+  for (int i = lane; i < atoms; i += 64) vm = fmaxf(vm, vl[i]);
+  vm = wave_max(vm);
+  float vs = 0.f;
+  for (int i = lane; i < atoms; i += 64) vs += __expf(vl[i] - vm);
+  vs = wave_sum(vs);
+  const float vlse = vm + __logf(vs);
+  float vc = 0.f;
+  const float cv = wv * w * invB;
+  for (int i = lane; i < atoms; i += 64) {
+    const float tgt = (i == lo ? mlo : 0.f) + (i == hi ? mhi : 0.f);
+    const float logq = vl[i] - vlse;
+    vc -= tgt * logq;
+    dvlog[(size_t)wave * atoms + i] = cv * (__expf(logq) - tgt);
+  }
+  vc = wave_sum(vc);
+  if (lane == 0) {
+    pce[wave] = ce;
+    vce[wave] = vc;
+    ent[wave] = H;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Two-stage deterministic sum of squares of the (scaled) flat gradient buffer.
+__global__ void sumsq_partial_kernel(const float* __restrict__ g, long long n, float scale, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    float4 v = *reinterpret_cast<const float4*>(g + i);  // buffers are padded to multiples of 64 floats
+    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ norm_out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) norm_out[0] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+
+// kind: 0 = Adam (L2 in the gradient), 1 = AdamW (decoupled decay), 2 = SGD with momentum.
+__global__ void flat_optimizer_kernel(int kind, float* __restrict__ p, const float* __restrict__ g,
+                                      float* __restrict__ m, float* __restrict__ v, long long n,
+                                      const float* __restrict__ norm, float lr, float b1, float b2, float eps,
+                                      float wd, float mom, float bc1, float bc2_sqrt, float max_norm,
+                                      float grad_scale, int first_step) {
+  float coef = grad_scale;
+  if (max_norm > 0.f) coef *= fminf(1.0f, max_norm / (norm[0] + 1e-6f));
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float pv = p[i];
+    float gv = g[i] * coef;
+    if (kind == 2) {
+      if (wd != 0.f) gv += wd * pv;
+      float mv = first_step ? gv : mom * m[i] + gv;
+      m[i] = mv;
+      p[i] = pv - lr * mv;
+    } else {
+      if (kind == 1) {
+        pv *= 1.0f - lr * wd;
+      } else if (wd != 0.f) {
+        gv += wd * pv;
+      }
+      const float mv = b1 * m[i] + (1.0f - b1) * gv;
+      const float vv = b2 * v[i] + (1.0f - b2) * gv * gv;
+      m[i] = mv;
+      v[i] = vv;
+      const float denom = sqrtf(vv) / bc2_sqrt + eps;
+      p[i] = pv - (lr / bc1) * (mv / denom);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Sum tree in HBM: power-of-two layout, root at 1, leaves at [P, 2P), float64 sums.
+__global__ void per_set_leaves_kernel(double* tree, long long P, const int* idx, const int* count_ptr, int count_max,
+                                      const float* prio_ptr) {
+  const int n = count_ptr ? min(*count_ptr, count_max) : count_max;
+  const double pr = (double)prio_ptr[0];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) tree[P + idx[i]] = pr;
+}
+
+// Recompute the ancestors of the given leaves, level by level, inside ONE workgroup (the
+// barrier between levels makes every level-k sum visible before level k-1 reads it).
+__global__ void per_update_paths_kernel(double* tree, long long P, int levels, const int* idx, const int* count_ptr,
+                                        int count_max) {
+  const int n = count_ptr ? min(*count_ptr, count_max) : count_max;
+  for (int base = 0; base < n; base += blockDim.x) {
+    const int i = base + threadIdx.x;
+    long long node = i < n ? P + idx[i] : 0;
+    for (int l = 0; l < levels; ++l) {
+      node >>= 1;
+      if (i < n) tree[node] = tree[2 * node] + tree[2 * node + 1];
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void per_rebuild_kernel(double* tree, long long P) {
+  for (long long level = P >> 1; level >= 1; level >>= 1) {
+    for (long long i = level + threadIdx.x; i < 2 * level; i += blockDim.x) tree[i] = tree[2 * i] + tree[2 * i + 1];
+    __syncthreads();
+  }
+}
+
+// Stratified proportional sampling of B leaves + importance weights normalised by the batch max.
+// Single workgroup, B <= blockDim.x.
+__global__ void per_sample_kernel(const double* tree, long long P, int size, int B, const float* rnd, float beta,
+                                  int* out_idx, float* out_w) {
+  __shared__ float red[16];
+  const int i = threadIdx.x;
+  float wgt = 0.f;
+  if (i < B) {
+    const double total = tree[1];
+    const double seg = total / (double)B;
+    double value = ((double)i + (double)rnd[i]) * seg;
+    long long node = 1;
+    while (node < P) {
+      const double left = tree[2 * node];
+      if (value <= left) {
+        node = 2 * node;
+      } else {
+        value -= left;
+        node = 2 * node + 1;
+      }
+    }
+    int leaf = (int)(node - P);
+    if (leaf >= size) leaf = size - 1;  // rounding at the upper edge of the mass
+    const double pr = tree[P + leaf];
+    const double prob = total > 0.0 ? pr / total : 0.0;
+    wgt = prob > 1e-9 ? (float)pow((double)size * prob, -(double)beta) : 0.f;
+    out_idx[i] = leaf;
+  }
+  float mx = wave_max(wgt);
+  if ((i & 63) == 0) red[i >> 6] = mx;
+  __syncthreads();
+  float gm = 0.f;
+  for (int k = 0; k < (blockDim.x >> 6); ++k) gm = fmaxf(gm, red[k]);
+  if (i < B) out_w[i] = gm > 1e-9f ? wgt / gm : 1.0f;
+}
+
+// priority = (|err| + eps)^alpha, written to the leaves; tracks the running maximum.
+__global__ void per_priorities_kernel(double* tree, long long P, const int* idx, const float* err, int n, float alpha,
+                                      float eps, float* max_prio) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float e = fabsf(err[i]);
+  float pr = powf(e + eps, alpha);
+  if (!(pr == pr) || pr < eps) pr = eps;            // NaN / underflow
+  if (isinf(pr)) pr = max_prio[0];                   // +inf -> current maximum
+  tree[P + idx[i]] = (double)pr;
+  atomicMax(reinterpret_cast<unsigned int*>(max_prio), __float_as_uint(pr));  // positive floats order like uints
+}
+
+extern "C" {
+
+int atri_az_loss(const float* plog, const float* vlog, const float* ptgt, const float* ret, const float* isw,
+                 float* pce, float* vce, float* ent, float* dplog, float* dvlog, int B, int A, int atoms, float vmin,
+                 float vmax, float wp, float wv, float we, hipStream_t s) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(az_loss_kernel, dim3((B + 3) / 4), dim3(256), 0, s, plog, vlog, ptgt, ret, isw, pce, vce, ent,
+                     dplog, dvlog, B, A, atoms, vmin, vmax, wp, wv, we);
+  return (int)hipGetLastError();
+}
+
+int atri_flat_optimizer(int kind, float* p, const float* g, float* m, float* v, long long n, float* norm_buf,
+                        float* partial, int partial_cap, float lr, float b1, float b2, float eps, float wd, float mom,
+                        float bc1, float bc2_sqrt, float max_norm, float grad_scale, int first_step, hipStream_t s) {
+  if (n <= 0) return 0;
+  if ((n & 3) != 0) return -10;
+  int nb = (int)((n / 4 + 255) / 256);
+  if (nb > partial_cap) nb = partial_cap;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, g, n, grad_scale, partial);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, partial, nb, norm_buf);
+  int ob = (int)((n + 255) / 256);
+  if (ob > 4096) ob = 4096;
+  hipLaunchKernelGGL(flat_optimizer_kernel, dim3(ob), dim3(256), 0, s, kind, p, g, m, v, n, norm_buf, lr, b1, b2, eps,
+                     wd, mom, bc1, bc2_sqrt, max_norm, grad_scale, first_step);
+  return (int)hipGetLastError();
+}
+
+int atri_per_set_leaves(double* tree, long long P, const int* idx, const int* count_ptr, int count_max,
+                        const float* prio_ptr, hipStream_t s) {
+  if (count_max <= 0) return 0;
+  int nb = (count_max + 255) / 256;
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(per_set_leaves_kernel, dim3(nb), dim3(256), 0, s, tree, P, idx, count_ptr, count_max, prio_ptr);
+  return (int)hipGetLastError();
+}
+int atri_per_update_paths(double* tree, long long P, const int* idx, const int* count_ptr, int count_max,
+                          hipStream_t s) {
+  if (count_max <= 0) return 0;
+  int levels = 0;
+  while ((1LL << levels) < P) ++levels;
+  hipLaunchKernelGGL(per_update_paths_kernel, dim3(1), dim3(1024), 0, s, tree, P, levels, idx, count_ptr, count_max);
+  return (int)hipGetLastError();
+}
+int atri_per_rebuild(double* tree, long long P, hipStream_t s) {
+  hipLaunchKernelGGL(per_rebuild_kernel, dim3(1), dim3(1024), 0, s, tree, P);
+  return (int)hipGetLastError();
+}
+int atri_per_sample(const double* tree, long long P, int size, int B, const float* rnd, float beta, int* out_idx,
+                    float* out_w, hipStream_t s) {
+  if (B <= 0 || B > 1024 || size <= 0) return -10;
+  int threads = ((B + 63) / 64) * 64;
+  hipLaunchKernelGGL(per_sample_kernel, dim3(1), dim3(threads), 0, s, tree, P, size, B, rnd, beta, out_idx, out_w);
+  return (int)hipGetLastError();
+}
+int atri_per_priorities(double* tree, long long P, const int* idx, const float* err, int n, float alpha, float eps,
+                        float* max_prio, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(per_priorities_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tree, P, idx, err, n, alpha, eps,
+                     max_prio);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,631 @@
+// Hand-written gfx950 inference kernels of the policy / value network.
+//
+// Network being evaluated: alphatriangle/nn/model.py:109-297 (conv stem, residual
+// blocks, pre-LN Transformer encoder, shared FC, policy head, C51 value head) with
+// BatchNorm folded into the preceding conv / linear weights and bf16 activations.
+//
+// Data layout: activations are NHWC bf16, i.e. a row-major [rows = B*H*W, C] matrix,
+// so every conv / linear layer is a GEMM over rows.
+//
+// tile_gemm_kernel - the workhorse.  One workgroup keeps the complete input tile
+// of up to 256 rows (two 8x15 samples) resident in LDS and produces all taps of a
+// 3x3 convolution (or a 1x1 / linear layer) from it: no im2col traffic, the only
+// streamed operand is the weight panel, which is pre-packed in MFMA fragment order
+// and read straight from L2 into registers (each weight byte once per workgroup).
+// MFMA shape v_mfma_f32_16x16x32_bf16 is used with the weights as the A operand and
+// the activations as the B operand, so a lane ends up holding 8 consecutive output
+// channels of one pixel and the epilogue (bias, residual, activation, positional
+// table, bf16 pack) stores 16 bytes per lane.  240 rows = 15 M-tiles of 16, so the
+// default grid wastes no MFMA rows.  64-lane waves: the four waves split the 128
+// output channels of a column block (32 each).
+#include "common.hpp"
+
+using namespace atrihip;
+
+struct TileGemmArgs {
+  const unsigned short* in;        // [rows_total, Cin] bf16
+  const unsigned short* w;         // packed fragments, see pack_gemm_weights in ops/inference.py
+  const float* bias;               // [n_blocks*128]
+  const unsigned short* residual;  // [rows_total, Cout] bf16 or nullptr
+  const float* post_add;           // [HW, Cout] f32 or nullptr (added after the activation)
+  const float* ln_g;               // [Cin] LayerNorm prologue (nullptr = none)
+  const float* ln_b;
+  void* out;                       // bf16 or f32, row stride out_stride elements
+  int rows_total, rows_per_wg, HW, H, W, Cin, Cout, taps, act, out_f32, out_stride, n_blocks, log2_cpr;
+  float ln_eps;
+};
+
+// Non-ReLU activations of eight values; kept out of line so the unrolled epilogue stays small.
+__device__ __noinline__ void act8_slow(float* v, int act) {
+  for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i], act);
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void tile_gemm_kernel(TileGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int row0 = blockIdx.x * a.rows_per_wg;
+  const int rows = min(a.rows_per_wg, a.rows_total - row0);
+  const int stride = a.Cin * 2 + 16;  // bytes per LDS row (16-byte pad breaks the 256-byte bank period)
+  const int zoff = MT * 16 * stride;  // one all-zero row serves out-of-image taps and padding rows
+
+  // ---- stage the input tile (coalesced 16-byte chunks) ----
+  {
+    const int cpr = 1 << a.log2_cpr;  // 16-byte chunks per row
+    const int nchunks = rows << a.log2_cpr;
+    for (int c = tid; c < nchunks; c += 256) {
+      int r = c >> a.log2_cpr, cc = c & (cpr - 1);
+      uint4 v = *reinterpret_cast<const uint4*>(a.in + (size_t)(row0 + r) * a.Cin + cc * 8);
+      *reinterpret_cast<uint4*>(smem + r * stride + cc * 16) = v;
+    }
+    for (int c = tid; c < (stride >> 4); c += 256) *reinterpret_cast<uint4*>(smem + zoff + c * 16) = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+
+  // ---- optional LayerNorm over Cin, in place (pre-LN Transformer blocks) ----
+  if (a.ln_g != nullptr) {
+    if (tid < rows) {
+      unsigned char* rowp = smem + tid * stride;
+      float s = 0.f, ss = 0.f;
+      for (int c = 0; c < (a.Cin >> 3); ++c) {
+        short8 v = *reinterpret_cast<const short8*>(rowp + c * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float x = bf16_to_float((unsigned short)v[j]);
+          s += x;
+          ss += x * x;
+        }
+      }
+      float mean = s / (float)a.Cin;
+      float var = fmaxf(ss / (float)a.Cin - mean * mean, 0.f);
+      float rstd = rsqrtf(var + a.ln_eps);
+      for (int c = 0; c < (a.Cin >> 3); ++c) {
+        short8 v = *reinterpret_cast<const short8*>(rowp + c * 16);
+        short8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float x = (bf16_to_float((unsigned short)v[j]) - mean) * rstd;
+          o[j] = (short)float_to_bf16(x * a.ln_g[c * 8 + j] + a.ln_b[c * 8 + j]);
+        }
+        *reinterpret_cast<short8*>(rowp + c * 16) = o;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-lane tile bookkeeping: LDS offset of "its" pixel + 9-bit tap validity ----
+  int packed[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int r = t * 16 + l15;
+    int mask = 0;
+    if (r < rows) {
+      if (a.taps == 9) {
+        int p = r % a.HW;
+        int y = p / a.W, x = p - y * a.W;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+          if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) mask |= 1 << tap;
+        }
+      } else {
+        mask = 1;
+      }
+    }
+    packed[t] = (r * stride + q4 * 16) | (mask << 18);
+  }
+
+  const int KC = a.Cin >> 5;
+  const int steps = a.taps * KC;
+  for (int nb = 0; nb < a.n_blocks; ++nb) {
+    const int ch_wave = nb * 128 + wave * 32;
+    if (ch_wave >= a.Cout) continue;  // wave-uniform
+    float4v acc[MT][2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
+      acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+    }
+    // fragment stream of this wave: [(nb*steps + s)][wave][n][lane] in short8 units
+    const short8* wp = reinterpret_cast<const short8*>(a.w) + ((size_t)nb * steps * 4 + wave) * 128 + lane;
+    short8 b0 = wp[0], b1 = wp[64];
+    int s = 0;
+    for (int tap = 0; tap < a.taps; ++tap) {
+      const int toff = (a.taps == 9) ? ((tap / 3 - 1) * a.W + (tap % 3 - 1)) * stride : 0;
+      const int tapbit = 18 + tap;
+      const int zlane = zoff + q4 * 16;
+      for (int kc = 0; kc < KC; ++kc, ++s) {
+        // prefetch the next step's weight fragments (the packed buffer carries one spare step)
+        const short8 nb0 = wp[(size_t)(s + 1) * 512];
+        const short8 nb1 = wp[(size_t)(s + 1) * 512 + 64];
+        const int koff = kc * 64;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int ad = ((packed[t] >> tapbit) & 1) ? (packed[t] & 0x3FFFF) + toff : zlane;
+          const short8 av = *reinterpret_cast<const short8*>(smem + ad + koff);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, av, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, av, acc[t][1], 0, 0, 0);
+          if ((t % 5) == 4) __builtin_amdgcn_sched_barrier(0);  // bound the LDS reads in flight (VGPR budget)
+        }
+        b0 = nb0;
+        b1 = nb1;
+      }
+    }
+
+    // ---- epilogue: lane owns channels ch0..ch0+7 of pixel (t*16 + l15) ----
+    const int ch0 = ch_wave + q4 * 8;
+    if (ch0 < a.Cout) {
+      float bias[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bias[i] = a.bias[ch0 + i];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        int r = t * 16 + l15;
+        asm volatile("" : "+v"(r));  // keep the per-row address math out of the MFMA loop's live range
+        if (r >= rows) continue;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[t][0][j] + bias[j];
+          v[4 + j] = acc[t][1][j] + bias[4 + j];
+        }
+        const size_t grow = (size_t)(row0 + r);
+        if (a.residual != nullptr) {
+          short8 rv = *reinterpret_cast<const short8*>(a.residual + grow * a.Cout + ch0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += bf16_to_float((unsigned short)rv[i]);
+        }
+        if (a.act == kActReLU) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        } else if (a.act != kActNone) {
+          act8_slow(v, a.act);
+        }
+        if (a.post_add != nullptr) {
+          const float* pa = a.post_add + (size_t)(r % a.HW) * a.Cout + ch0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += pa[i];
+        }
+        if (a.out_f32) {
+          float* op = reinterpret_cast<float*>(a.out) + grow * a.out_stride + ch0;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          short8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (short)float_to_bf16(v[i]);
+          *reinterpret_cast<short8*>(reinterpret_cast<unsigned short*>(a.out) + grow * a.out_stride + ch0) = o;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// First conv layer: Cin = 1, direct 3x3 on the f32 grid -> bf16 NHWC.  Memory bound.
+// One thread per (row, 8 output channels).
+__global__ void conv_first_kernel(const float* __restrict__ grid, const float* __restrict__ w /*[9][Cout]*/,
+                                  const float* __restrict__ bias, unsigned short* __restrict__ out, int rows_total,
+                                  int HW, int H, int W, int Cout, int act) {
+  const int groups = Cout >> 3;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)rows_total * groups) return;
+  const int row = (int)(idx / groups), g = (int)(idx - (long long)row * groups);
+  const int p = row % HW, y = p / W, x = p - y * W;
+  const float* gs = grid + (size_t)(row - p);
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = bias[g * 8 + i];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+    float gv = gs[yy * W + xx];
+    const float* wp = w + tap * Cout + g * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += gv * wp[i];
+  }
+  short8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (short)float_to_bf16(apply_act(v[i], act));
+  *reinterpret_cast<short8*>(out + (size_t)row * Cout + g * 8) = o;
+}
+
+// ---------------------------------------------------------------------------
+// Multi-head self-attention over one sample's tokens, head_dim = 32, no mask.
+// One wave per (sample, head).  S^T = K Q^T is computed with the KEY on the MFMA
+// row, so the softmax row reduction is in-lane plus two shuffles and the
+// probability tile feeds the P.V product as the B operand straight from registers
+// (only V goes through LDS, to gather its column-major fragments).
+// qkv: [B, HW, 3*D] bf16 (Q pre-scaled by 1/sqrt(32)), out: [B, HW, D] bf16.
+template <int NKT>
+__global__ __launch_bounds__(256) void attention_kernel(const unsigned short* __restrict__ qkv,
+                                                        unsigned short* __restrict__ out, int B, int HW, int D,
+                                                        int heads) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int VSTRIDE = 80;  // bytes per staged V row (64 + 16 pad)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.x;
+  unsigned char* vl = smem + wave * (NKT * 16 * VSTRIDE);
+  const size_t rs = (size_t)3 * D;  // row stride in elements
+  const unsigned short* base = qkv + (size_t)b * HW * rs;
+
+  for (int head = wave; head < heads; head += 4) {
+    // stage V[token][32] of this head
+    for (int c = lane; c < NKT * 16 * 4; c += 64) {
+      int tok = c >> 2, ch = c & 3;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (tok < HW) v = *reinterpret_cast<const uint4*>(base + tok * rs + 2 * D + head * 32 + ch * 8);
+      *reinterpret_cast<uint4*>(vl + tok * VSTRIDE + ch * 16) = v;
+    }
+    // K fragments (A operand): K[token 16kt + l15][dims 8q4 .. 8q4+7]
+    short8 kf[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      int tok = kt * 16 + l15;
+      kf[kt] = (short8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (tok < HW) kf[kt] = *reinterpret_cast<const short8*>(base + tok * rs + D + head * 32 + q4 * 8);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // V^T fragments (A operand of P.V): element e of lane group q4 in key block kb is
+    // key 32kb + (e<4 ? 4q4+e : 16+4q4+e-4), matching the register order of the S^T tiles.
+    short8 vf[NKT / 2][2];
+#pragma unroll
+    for (int kb = 0; kb < NKT / 2; ++kb)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        short8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          int key = 32 * kb + (e < 4 ? 4 * q4 + e : 16 + 4 * q4 + (e - 4));
+          f[e] = *reinterpret_cast<const short*>(vl + key * VSTRIDE + (dt * 16 + l15) * 2);
+        }
+        vf[kb][dt] = f;
+      }
+
+    const int n_qt = (HW + 15) >> 4;
+    for (int qt = 0; qt < n_qt; ++qt) {
+      const int qtok = qt * 16 + l15;
+      short8 qf = (short8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (qtok < HW) qf = *reinterpret_cast<const short8*>(base + qtok * rs + head * 32 + q4 * 8);
+      float4v st[NKT];
+      float m = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf, (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int key = kt * 16 + q4 * 4 + j;
+          if (key >= HW) st[kt][j] = -1e30f;
+          m = fmaxf(m, st[kt][j]);
+        }
+      }
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float p = __expf(st[kt][j] - m);
+          st[kt][j] = p;
+          sum += p;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+      float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NKT / 2; ++kb) {
+        short8 pf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pf[j] = (short)float_to_bf16(st[2 * kb][j]);
+          pf[4 + j] = (short)float_to_bf16(st[2 * kb + 1][j]);
+        }
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb][0], pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb][1], pf, o1, 0, 0, 0);
+      }
+      if (qtok < HW) {
+        unsigned short* op = out + ((size_t)b * HW + qtok) * D + head * 32 + q4 * 4;
+        ushort4 w0, w1;
+        w0.x = float_to_bf16(o0[0] * inv); w0.y = float_to_bf16(o0[1] * inv);
+        w0.z = float_to_bf16(o0[2] * inv); w0.w = float_to_bf16(o0[3] * inv);
+        w1.x = float_to_bf16(o1[0] * inv); w1.y = float_to_bf16(o1[1] * inv);
+        w1.z = float_to_bf16(o1[2] * inv); w1.w = float_to_bf16(o1[3] * inv);
+        *reinterpret_cast<ushort4*>(op) = w0;
+        *reinterpret_cast<ushort4*>(op + 16) = w1;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Row LayerNorm (or plain copy when gamma == nullptr) of [rows, D] bf16 into the FC input
+// buffer: sample b, pixel p lands at dst[b*dst_stride + p*D .. +D).  16 lanes per row.
+__global__ void rows_to_fc_kernel(const unsigned short* __restrict__ src, const float* __restrict__ g,
+                                  const float* __restrict__ bt, unsigned short* __restrict__ dst, int rows_total,
+                                  int HW, int D, int dst_stride, float eps) {
+  const int lane16 = threadIdx.x & 15;
+  const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (row >= rows_total) return;  // whole 16-lane group exits together
+  const int b = (int)(row / HW), p = (int)(row - (long long)b * HW);
+  const unsigned short* sp = src + (size_t)row * D;
+  unsigned short* dp = dst + (size_t)b * dst_stride + (size_t)p * D;
+  float s = 0.f, ss = 0.f;
+  if (g != nullptr) {
+    for (int c = lane16; c < (D >> 3); c += 16) {
+      short8 v = *reinterpret_cast<const short8*>(sp + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = bf16_to_float((unsigned short)v[j]);
+        s += x;
+        ss += x * x;
+      }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      s += __shfl_xor(s, off, 64);
+      ss += __shfl_xor(ss, off, 64);
+    }
+  }
+  const float mean = s / (float)D;
+  const float rstd = rsqrtf(fmaxf(ss / (float)D - mean * mean, 0.f) + eps);
+  for (int c = lane16; c < (D >> 3); c += 16) {
+    short8 v = *reinterpret_cast<const short8*>(sp + c * 8);
+    if (g != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = (bf16_to_float((unsigned short)v[j]) - mean) * rstd;
+        v[j] = (short)float_to_bf16(x * g[c * 8 + j] + bt[c * 8 + j]);
+      }
+    }
+    *reinterpret_cast<short8*>(dp + c * 8) = v;
+  }
+}
+
+// "other" features f32 [B, Do] -> bf16 into the tail columns of the FC input buffer (zero padded).
+__global__ void other_to_fc_kernel(const float* __restrict__ other, unsigned short* __restrict__ dst, int B, int Do,
+                                   int Dpad, int dst_stride, int col0) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * Dpad) return;
+  const int b = (int)(idx / Dpad), c = (int)(idx - (long long)b * Dpad);
+  float v = c < Do ? other[(size_t)b * Do + c] : 0.f;
+  dst[(size_t)b * dst_stride + col0 + c] = float_to_bf16(v);
+}
+
+// ---------------------------------------------------------------------------
+// Shared FC over the flattened body: out[b][n] = sum_k X[b][k] W[k][n], K ~ 15k, N <= 128.
+// Split-K over blockIdx.y into f32 slabs [SK][B][128] (summed, deterministically, by fc_finish).
+// Workgroup tile: 64 samples x 128 outputs; X chunks of 128 k go through LDS, weights come
+// as packed fragments from L2.
+__global__ __launch_bounds__(256, 2) void fc_splitk_kernel(const unsigned short* __restrict__ X,
+                                                           const unsigned short* __restrict__ Wp,
+                                                           float* __restrict__ slabs, int B, int Kp, int N,
+                                                           int steps_per_split) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs[64 * 272];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b0 = blockIdx.x * 64;
+  const int total_steps = Kp >> 5;
+  const int s_begin = blockIdx.y * steps_per_split;
+  const int s_end = min(s_begin + steps_per_split, total_steps);
+  float4v acc[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
+    acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool wave_active = wave * 32 < N;
+  const short8* wp = reinterpret_cast<const short8*>(Wp) + (size_t)wave * 128 + lane;
+  for (int s0 = s_begin; s0 < s_end; s0 += 4) {
+    // stage X[64 samples][128 k] (zero beyond the batch / the split's K range)
+    __syncthreads();
+    for (int c = tid; c < 64 * 16; c += 256) {
+      int r = c >> 4, cc = c & 15;
+      int step = s0 + (cc >> 2);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b0 + r < B && step < s_end) v = *reinterpret_cast<const uint4*>(X + (size_t)(b0 + r) * Kp + (size_t)s0 * 32 + cc * 8);
+      *reinterpret_cast<uint4*>(xs + r * 272 + cc * 16) = v;
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int step = s0 + ks;
+      if (step >= s_end) break;
+      const short8 w0 = wp[(size_t)step * 512];
+      const short8 w1 = wp[(size_t)step * 512 + 64];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const short8 xv = *reinterpret_cast<const short8*>(xs + (t * 16 + l15) * 272 + ks * 64 + q4 * 16);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xv, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xv, acc[t][1], 0, 0, 0);
+      }
+    }
+  }
+  if (!wave_active) return;
+  float* slab = slabs + (size_t)blockIdx.y * B * 128;
+  const int ch0 = wave * 32 + q4 * 8;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int bi = b0 + t * 16 + l15;
+    if (bi >= B) continue;
+    float* op = slab + (size_t)bi * 128 + ch0;
+    *reinterpret_cast<float4*>(op) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
+    *reinterpret_cast<float4*>(op + 4) = make_float4(acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]);
+  }
+}
+
+// h[b][n] = act(sum_s slabs[s][b][n] + bias[n]) -> bf16 [B, N]
+__global__ void fc_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ bias,
+                                 unsigned short* __restrict__ out, int B, int N, int SK, int act) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * N) return;
+  const int b = (int)(idx / N), n = (int)(idx - (long long)b * N);
+  float v = bias[n];
+  for (int s = 0; s < SK; ++s) v += slabs[((size_t)s * B + b) * 128 + n];
+  out[(size_t)b * N + n] = float_to_bf16(apply_act(v, act));
+}
+
+// C51 expectation: value[b] = sum_i softmax(logits[b])_i * (vmin + i*dz)
+__global__ void c51_expect_kernel(const float* __restrict__ logits, int stride, int atoms, float vmin, float dz,
+                                  float* __restrict__ value, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* lp = logits + (size_t)b * stride;
+  float m = -1e30f;
+  for (int i = 0; i < atoms; ++i) m = fmaxf(m, lp[i]);
+  float s = 0.f, e = 0.f;
+  for (int i = 0; i < atoms; ++i) {
+    float p = __expf(lp[i] - m);
+    s += p;
+    e += p * (vmin + dz * (float)i);
+  }
+  value[b] = e / s;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+extern "C" {
+
+int atri_tile_gemm(const void* in, const void* w, const float* bias, const void* residual, const float* post_add,
+                   const float* ln_g, const float* ln_b, void* out, int rows_total, int rows_per_wg, int HW, int H,
+                   int W, int Cin, int Cout, int taps, int act, int out_f32, int out_stride, int n_blocks,
+                   float ln_eps, hipStream_t stream) {
+  if (rows_total <= 0) return 0;
+  if (Cin < 32 || (Cin & (Cin - 1)) != 0 || Cin > 512) return -10;
+  if (rows_per_wg <= 0 || rows_per_wg > 256) return -11;
+  if (taps != 1 && taps != 9) return -12;
+  if ((Cout & 7) != 0 || n_blocks * 128 < Cout) return -13;
+  TileGemmArgs a;
+  a.in = (const unsigned short*)in;
+  a.w = (const unsigned short*)w;
+  a.bias = bias;
+  a.residual = (const unsigned short*)residual;
+  a.post_add = post_add;
+  a.ln_g = ln_g;
+  a.ln_b = ln_b;
+  a.out = out;
+  a.rows_total = rows_total;
+  a.rows_per_wg = rows_per_wg;
+  a.HW = HW;
+  a.H = H;
+  a.W = W;
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.taps = taps;
+  a.act = act;
+  a.out_f32 = out_f32;
+  a.out_stride = out_stride;
+  a.n_blocks = n_blocks;
+  int l2 = 0;
+  while ((1 << l2) < (Cin >> 3)) ++l2;
+  a.log2_cpr = l2;
+  a.ln_eps = ln_eps;
+  const int grid = (rows_total + rows_per_wg - 1) / rows_per_wg;
+  const int stride = Cin * 2 + 16;
+  // the dynamic-LDS ceiling is raised once per kernel (not a stream operation: keep it out of graph capture)
+  static bool attr15 = false, attr16 = false;
+  if (rows_per_wg <= 240) {
+    size_t lds = (size_t)(15 * 16 + 1) * stride;
+    if (!attr15) {
+      hipFuncSetAttribute((const void*)tile_gemm_kernel<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr15 = true;
+    }
+    hipLaunchKernelGGL(tile_gemm_kernel<15>, dim3(grid), dim3(256), lds, stream, a);
+  } else {
+    size_t lds = (size_t)(16 * 16 + 1) * stride;
+    if (!attr16) {
+      hipFuncSetAttribute((const void*)tile_gemm_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr16 = true;
+    }
+    hipLaunchKernelGGL(tile_gemm_kernel<16>, dim3(grid), dim3(256), lds, stream, a);
+  }
+  return hip_err(hipGetLastError());
+}
+
+int atri_conv_first(const float* grid, const float* w, const float* bias, void* out, int rows_total, int HW, int H,
+                    int W, int Cout, int act, hipStream_t stream) {
+  if (rows_total <= 0) return 0;
+  if ((Cout & 7) != 0) return -10;
+  long long n = (long long)rows_total * (Cout >> 3);
+  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, grid, w, bias,
+                     (unsigned short*)out, rows_total, HW, H, W, Cout, act);
+  return hip_err(hipGetLastError());
+}
+
+int atri_attention(const void* qkv, void* out, int B, int HW, int D, int heads, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (D != heads * 32) return -10;
+  if (HW <= 128) {
+    size_t lds = (size_t)4 * 8 * 16 * 80;
+    hipLaunchKernelGGL(attention_kernel<8>, dim3(B), dim3(256), lds, stream, (const unsigned short*)qkv,
+                       (unsigned short*)out, B, HW, D, heads);
+  } else if (HW <= 256) {
+    size_t lds = (size_t)4 * 16 * 16 * 80;
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute((const void*)attention_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL(attention_kernel<16>, dim3(B), dim3(256), lds, stream, (const unsigned short*)qkv,
+                       (unsigned short*)out, B, HW, D, heads);
+  } else {
+    return -11;
+  }
+  return hip_err(hipGetLastError());
+}
+
+int atri_rows_to_fc(const void* src, const float* g, const float* bt, void* dst, int rows_total, int HW, int D,
+                    int dst_stride, float eps, hipStream_t stream) {
+  if (rows_total <= 0) return 0;
+  if ((D & 7) != 0) return -10;
+  long long threads = (long long)rows_total * 16;
+  hipLaunchKernelGGL(rows_to_fc_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
+                     (const unsigned short*)src, g, bt, (unsigned short*)dst, rows_total, HW, D, dst_stride, eps);
+  return hip_err(hipGetLastError());
+}
+
+int atri_other_to_fc(const float* other, void* dst, int B, int Do, int Dpad, int dst_stride, int col0,
+                     hipStream_t stream) {
+  if (B <= 0) return 0;
+  long long n = (long long)B * Dpad;
+  hipLaunchKernelGGL(other_to_fc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, other,
+                     (unsigned short*)dst, B, Do, Dpad, dst_stride, col0);
+  return hip_err(hipGetLastError());
+}
+
+int atri_fc_splitk(const void* X, const void* Wp, float* slabs, int B, int Kp, int N, int SK, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if ((Kp & 31) != 0 || N > 128 || (N & 7) != 0 || SK < 1) return -10;
+  int total_steps = Kp >> 5;
+  int per = (total_steps + SK - 1) / SK;
+  per = (per + 3) & ~3;
+  hipLaunchKernelGGL(fc_splitk_kernel, dim3((B + 63) / 64, SK), dim3(256), 0, stream, (const unsigned short*)X,
+                     (const unsigned short*)Wp, slabs, B, Kp, N, per);
+  return hip_err(hipGetLastError());
+}
+
+int atri_fc_finish(const float* slabs, const float* bias, void* out, int B, int N, int SK, int act,
+                   hipStream_t stream) {
+  if (B <= 0) return 0;
+  long long n = (long long)B * N;
+  hipLaunchKernelGGL(fc_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slabs, bias,
+                     (unsigned short*)out, B, N, SK, act);
+  return hip_err(hipGetLastError());
+}
+
+int atri_c51_expect(const float* logits, int stride, int atoms, float vmin, float dz, float* value, int B,
+                    hipStream_t stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(c51_expect_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, stride, atoms, vmin, dz,
+                     value, B);
+  return hip_err(hipGetLastError());
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""Python face of the learner-side HIP kernels (csrc/hip/learner_kernels.hip)."""
+
+from __future__ import annotations
+
+import torch
+
+from .. import native
+from . import hipbind as hb
+from .losses import LossOutputs
+
+_KIND = {"Adam": 0, "AdamW": 1, "SGD": 2}
+
+
+def available() -> bool:
+    return native.hip_available()
+
+
+def require() -> None:
+    hb.lib()
+
+
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plog, vlog, ptgt, ret, isw, v_min, v_max, wp, wv, we):  # noqa: ANN001
+        B, A = plog.shape
+        atoms = vlog.shape[1]
+        pl = plog.detach().float().contiguous()
+        vl = vlog.detach().float().contiguous()
+        pt = ptgt.detach().float().contiguous()
+        rt = ret.detach().float().contiguous()
+        iw = isw.detach().float().contiguous()
+        dev = pl.device
+        pce = torch.empty(B, dtype=torch.float32, device=dev)
+        vce = torch.empty(B, dtype=torch.float32, device=dev)
+        ent = torch.empty(B, dtype=torch.float32, device=dev)
+        dpl = torch.empty_like(pl)
+        dvl = torch.empty_like(vl)
+        hb.call(
+            "atri_az_loss", hb.ptr(pl), hb.ptr(vl), hb.ptr(pt), hb.ptr(rt), hb.ptr(iw), hb.ptr(pce), hb.ptr(vce),
+            hb.ptr(ent), hb.ptr(dpl), hb.ptr(dvl), hb.i32(B), hb.i32(A), hb.i32(atoms), hb.f32(v_min), hb.f32(v_max),
+            hb.f32(wp), hb.f32(wv), hb.f32(we),
+        )
+        ctx.save_for_backward(dpl, dvl)
+        ctx.in_dtypes = (plog.dtype, vlog.dtype)
+        policy_loss = (pce * iw).mean()
+        value_loss = (vce * iw).mean()
+        entropy = ent.mean() if we > 0 else torch.zeros((), device=dev)
+        total = wp * policy_loss + wv * value_loss - we * entropy
+        ctx.mark_non_differentiable(policy_loss, value_loss, entropy, vce)
+        return total, policy_loss, value_loss, entropy, vce
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):  # noqa: ANN001
+        dpl, dvl = ctx.saved_tensors
+        pd, vd = ctx.in_dtypes
+        return (dpl * g_total).to(pd), (dvl * g_total).to(vd), None, None, None, None, None, None, None, None
+
+
+def fused_loss(policy_logits, value_logits, policy_target, returns, is_weights, *, v_min, v_max, policy_weight,
+               value_weight, entropy_weight) -> LossOutputs:  # noqa: ANN001
+    total, pl, vl, ent, td = _FusedLoss.apply(
+        policy_logits, value_logits, policy_target, returns, is_weights, float(v_min), float(v_max),
+        float(policy_weight), float(value_weight), float(entropy_weight),
+    )
+    return LossOutputs(total, pl, vl, ent, td)
+
+
+_partial_cache: dict[torch.device, torch.Tensor] = {}
+
+
+def flat_optimizer_step(*, kind: str, param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor | None,
+                        norm_buf: torch.Tensor, step: int, lr: float, beta1: float, beta2: float, eps: float,
+                        weight_decay: float, momentum: float, max_grad_norm: float | None, grad_scale: float) -> torch.Tensor:
+    """Gradient-norm clip + optimizer update of the whole flat buffer; returns the (device) gradient norm."""
+    dev = param.device
+    partial = _partial_cache.get(dev)
+    if partial is None:
+        partial = torch.empty(1024, dtype=torch.float32, device=dev)
+        _partial_cache[dev] = partial
+    bc1 = 1.0 - beta1**step
+    bc2 = 1.0 - beta2**step
+    hb.call(
+        "atri_flat_optimizer", hb.i32(_KIND[kind]), hb.ptr(param), hb.ptr(grad), hb.ptr(m), hb.ptr(v if v is not None else m),
+        hb.i64(param.numel()), hb.ptr(norm_buf), hb.ptr(partial), hb.i32(1024), hb.f32(lr), hb.f32(beta1), hb.f32(beta2),
+        hb.f32(eps), hb.f32(weight_decay), hb.f32(momentum), hb.f32(bc1), hb.f32(bc2**0.5),
+        hb.f32(max_grad_norm if max_grad_norm is not None else 0.0), hb.f32(grad_scale), hb.i32(1 if step == 1 else 0),
+    )
+    return norm_buf[0]
+
+
+# ---------------------------------------------------------------- prioritized replay tree
+def per_set_leaves(tree: torch.Tensor, P: int, idx: torch.Tensor, count: torch.Tensor | None, count_max: int, prio: torch.Tensor) -> None:
+    hb.call("atri_per_set_leaves", hb.ptr(tree), hb.i64(P), hb.ptr(idx), hb.ptr(count), hb.i32(count_max), hb.ptr(prio))
+
+
+def per_update_paths(tree: torch.Tensor, P: int, idx: torch.Tensor, count: torch.Tensor | None, count_max: int) -> None:
+    hb.call("atri_per_update_paths", hb.ptr(tree), hb.i64(P), hb.ptr(idx), hb.ptr(count), hb.i32(count_max))
+
+
+def per_rebuild(tree: torch.Tensor, P: int) -> None:
+    hb.call("atri_per_rebuild", hb.ptr(tree), hb.i64(P))
+
+
+def per_sample(tree: torch.Tensor, P: int, size: int, batch: int, rnd: torch.Tensor, beta: float, out_idx: torch.Tensor, out_w: torch.Tensor) -> None:
+    hb.call("atri_per_sample", hb.ptr(tree), hb.i64(P), hb.i32(size), hb.i32(batch), hb.ptr(rnd), hb.f32(beta), hb.ptr(out_idx), hb.ptr(out_w))
+
+
+def per_priorities(tree: torch.Tensor, P: int, idx: torch.Tensor, err: torch.Tensor, alpha: float, eps: float, max_prio: torch.Tensor) -> None:
+    hb.call("atri_per_priorities", hb.ptr(tree), hb.i64(P), hb.ptr(idx), hb.ptr(err), hb.i32(idx.numel()), hb.f32(alpha), hb.f32(eps), hb.ptr(max_prio))

@@ -1,0 +1,458 @@
+"""Hand-written HIP inference engine for :class:`AlphaTriangleNet` on gfx950.
+
+``InferenceEngine.load_from_module`` folds every BatchNorm into the preceding
+conv / linear layer, converts weights to bf16 and packs them in MFMA fragment
+order; ``forward`` then evaluates the network with the kernels of
+``csrc/hip/nn_kernels.hip`` (about 25 launches, no PyTorch ops).  The numerical
+reference is the eval-mode PyTorch module (models/model.py); the network itself
+is the reference's (alphatriangle/nn/model.py:109-297).
+
+Layer -> kernel map (default config, B leaves, HW = 120 tokens):
+  conv stem layer 0 (Cin = 1)            conv_first_kernel        (VALU, memory bound)
+  conv stem 1.., residual convs          tile_gemm_kernel taps=9  (MFMA implicit GEMM)
+  1x1 projections, QKV, out-proj, FFN    tile_gemm_kernel taps=1  (+LayerNorm prologue,
+                                         residual / activation / positional epilogue)
+  4-head attention                       attention_kernel         (MFMA, softmax in registers)
+  final LayerNorm + flatten              rows_to_fc_kernel
+  shared FC (K = 15390)                  fc_splitk_kernel + fc_finish_kernel
+  policy / value heads                   tile_gemm_kernel taps=1 (rows = samples)
+  C51 expectation                        c51_expect_kernel
+"""
+
+from __future__ import annotations
+
+import logging
+import math
+from dataclasses import dataclass
+from typing import Any
+
+import torch
+import torch.nn as nn
+
+from ..config.env_config import EnvConfig
+from ..config.model_config import ModelConfig
+from . import hipbind as hb
+
+logger = logging.getLogger(__name__)
+
+ACT_IDS = {"none": 0, "ReLU": 1, "GELU": 2, "SiLU": 3, "Tanh": 4, "Sigmoid": 5}
+
+
+def _pow2(x: int) -> bool:
+    return x > 0 and (x & (x - 1)) == 0
+
+
+def engine_supports(mc: ModelConfig, ec: EnvConfig) -> tuple[bool, str]:
+    """Whether the HIP engine implements this architecture (else callers use the PyTorch module)."""
+    if mc.GRID_INPUT_CHANNELS != 1:
+        return False, "GRID_INPUT_CHANNELS != 1"
+    if not mc.CONV_FILTERS:
+        return False, "no conv stem"
+    for k, s, p in zip(mc.CONV_KERNEL_SIZES, mc.CONV_STRIDES, mc.CONV_PADDING, strict=True):
+        if k not in (3, (3, 3)) or s not in (1, (1, 1)) or p not in (1, (1, 1)):
+            return False, "conv stem must be 3x3 / stride 1 / padding 1"
+    chans = list(mc.CONV_FILTERS)
+    if mc.NUM_RESIDUAL_BLOCKS > 0:
+        chans.append(mc.RESIDUAL_BLOCK_FILTERS)
+    if chans[0] % 8 != 0:
+        return False, "first conv width must be a multiple of 8"
+    for c in chans:
+        if not (_pow2(c) and 32 <= c <= 512):
+            return False, f"channel width {c} must be a power of two in [32, 512]"
+    hw = ec.ROWS * ec.COLS
+    if hw > 256:
+        return False, "more than 256 cells"
+    uses_tf = mc.USE_TRANSFORMER and mc.TRANSFORMER_LAYERS > 0
+    if uses_tf:
+        d = mc.TRANSFORMER_DIM
+        if not (_pow2(d) and 32 <= d <= 512) or d // mc.TRANSFORMER_HEADS != 32:
+            return False, "transformer needs power-of-two dim with head_dim 32"
+        if not (_pow2(mc.TRANSFORMER_FC_DIM) and 32 <= mc.TRANSFORMER_FC_DIM <= 512):
+            return False, "TRANSFORMER_FC_DIM must be a power of two in [32, 512]"
+        if mc.ACTIVATION_FUNCTION not in ("ReLU", "GELU"):
+            return False, "transformer activation must be ReLU or GELU"
+    if not mc.FC_DIMS_SHARED:
+        return False, "FC_DIMS_SHARED must not be empty"
+    if mc.FC_DIMS_SHARED[0] > 128 or mc.FC_DIMS_SHARED[0] % 32 != 0:
+        return False, "first shared FC width must be a multiple of 32 and <= 128"
+    for w in [*mc.FC_DIMS_SHARED, *mc.POLICY_HEAD_DIMS, *mc.VALUE_HEAD_DIMS]:
+        if not (_pow2(w) and 32 <= w <= 512):
+            return False, f"dense width {w} must be a power of two in [32, 512]"
+    if (ec.NUM_SHAPE_SLOTS * hw) % 8 != 0:
+        return False, "action_dim must be a multiple of 8"
+    return True, ""
+
+
+_pack_index_cache: dict[tuple[int, int, int, str], tuple[torch.Tensor, int]] = {}
+
+
+def _pack_index(taps: int, cin: int, cout: int, device: torch.device) -> tuple[torch.Tensor, int]:
+    """Flat gather indices into the zero-padded ``[taps, cin, NB*128]`` weight for the fragment layout."""
+    key = (taps, cin, cout, str(device))
+    hit = _pack_index_cache.get(key)
+    if hit is not None:
+        return hit
+    assert cin % 32 == 0
+    kc_n = cin // 32
+    nb_n = (cout + 127) // 128
+    lane = torch.arange(64)
+    j = torch.arange(8)
+    kidx = torch.arange(kc_n)[:, None, None] * 32 + 8 * (lane[None, :, None] >> 4) + j[None, None, :]  # [KC,64,8]
+    r = lane & 15
+    cidx = (
+        torch.arange(nb_n)[:, None, None, None] * 128
+        + torch.arange(4)[None, :, None, None] * 32
+        + ((r >> 2) * 8)[None, None, None, :]
+        + torch.arange(2)[None, None, :, None] * 4
+        + (r & 3)[None, None, None, :]
+    )  # [NB,4,2,64]
+    shape = (nb_n, taps, kc_n, 4, 2, 64, 8)
+    k_full = kidx[None, None, :, None, None, :, :].expand(shape)
+    c_full = cidx[:, None, None, :, :, :, None].expand(shape)
+    t_full = torch.arange(taps)[None, :, None, None, None, None, None].expand(shape)
+    flat = ((t_full * cin + k_full) * (nb_n * 128) + c_full).reshape(-1).to(device)
+    _pack_index_cache[key] = (flat, nb_n)
+    return flat, nb_n
+
+
+def pack_gemm_weights(w: torch.Tensor, device: torch.device) -> tuple[torch.Tensor, int]:
+    """``w[taps, Cin, Cout]`` (f32) -> bf16 fragments ``[NB][taps*KC][wave 4][n 2][lane 64][8]`` (+1 spare step).
+
+    Fragment element ``j`` of lane ``l`` is ``W[k = kc*32 + 8*(l>>4) + j][cout]`` with
+    ``cout = nb*128 + wave*32 + (r>>2)*8 + n*4 + (r&3)``, ``r = l & 15``: after the MFMA
+    a lane then holds eight consecutive output channels of one pixel.  Runs on ``device``.
+    """
+    taps, cin, cout = w.shape
+    flat, nb_n = _pack_index(taps, cin, cout, device)
+    wpad = torch.zeros(taps, cin, nb_n * 128, dtype=torch.float32, device=device)
+    wpad[:, :, :cout] = w.detach().to(device=device, dtype=torch.float32)
+    packed = wpad.reshape(-1)[flat]
+    out = torch.cat([packed, torch.zeros(4 * 2 * 64 * 8, dtype=torch.float32, device=device)]).to(torch.bfloat16)
+    return out, nb_n
+
+
+def _fold_bn(weight: torch.Tensor, bias: torch.Tensor | None, bn: nn.Module | None) -> tuple[torch.Tensor, torch.Tensor]:
+    """Fold an eval-mode BatchNorm into ``weight`` (out-channel first) and ``bias``."""
+    w = weight.detach().float()
+    b = bias.detach().float() if bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if bn is not None and not isinstance(bn, nn.Identity):
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+        w = w * scale.view(-1, *([1] * (w.dim() - 1)))
+        b = b * scale + shift
+    return w, b
+
+
+@dataclass
+class _GemmLayer:
+    w: torch.Tensor
+    bias: torch.Tensor
+    cin: int
+    cout: int       # padded to a multiple of 8
+    taps: int
+    act: int
+    n_blocks: int
+    ln_g: torch.Tensor | None = None
+    ln_b: torch.Tensor | None = None
+    ln_eps: float = 1e-5
+    post_add: torch.Tensor | None = None
+
+
+def _split_seq(seq: nn.Sequential) -> list[tuple[nn.Module, nn.Module | None, bool]]:
+    """Group a Sequential of (Linear|Conv, [BN], [act]) into ``(layer, bn, has_act)`` triples."""
+    out: list[tuple[nn.Module, nn.Module | None, bool]] = []
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        layer = mods[i]
+        bn = None
+        has_act = False
+        i += 1
+        if i < len(mods) and isinstance(mods[i], (nn.BatchNorm1d, nn.BatchNorm2d)):
+            bn = mods[i]
+            i += 1
+        if i < len(mods) and not isinstance(mods[i], (nn.Linear, nn.Conv2d)):
+            has_act = True
+            i += 1
+        out.append((layer, bn, has_act))
+    return out
+
+
+class InferenceEngine:
+    def __init__(self, model_config: ModelConfig, env_config: EnvConfig, device: torch.device):
+        ok, why = engine_supports(model_config, env_config)
+        if not ok:
+            raise ValueError(f"HIP inference engine does not support this config: {why}")
+        hb.lib()  # fail loudly when the kernel library is missing
+        self.mc = model_config
+        self.ec = env_config
+        self.device = torch.device(device)
+        self.H, self.W = env_config.ROWS, env_config.COLS
+        self.HW = self.H * self.W
+        self.A = env_config.NUM_SHAPE_SLOTS * self.HW
+        self.act = ACT_IDS[model_config.ACTIVATION_FUNCTION]
+        self.other_dim = model_config.OTHER_NN_INPUT_FEATURES_DIM
+        self.other_pad = (self.other_dim + 31) // 32 * 32
+        self.rows_per_wg = max(1, 256 // self.HW) * self.HW if self.HW <= 256 else self.HW
+        if self.rows_per_wg > 240 and self.HW <= 240:
+            self.rows_per_wg = (240 // self.HW) * self.HW
+        self.uses_tf = bool(model_config.USE_TRANSFORMER and model_config.TRANSFORMER_LAYERS > 0)
+        self.logit_stride = self.A
+        self.value_stride = (model_config.NUM_VALUE_ATOMS + 7) // 8 * 8
+        self.cap = 0
+        self.loaded = False
+        self.fc_sk = 8
+        self._store: list[torch.Tensor] = []
+        self._store_cursor = 0
+
+    # ------------------------------------------------------------------ weights
+    def _put(self, value: torch.Tensor) -> torch.Tensor:
+        """Device tensor with a stable address across reloads (HIP graphs keep raw pointers)."""
+        i = self._store_cursor
+        self._store_cursor += 1
+        value = value.to(self.device)
+        if i < len(self._store) and self._store[i].shape == value.shape and self._store[i].dtype == value.dtype:
+            self._store[i].copy_(value)
+            return self._store[i]
+        value = value.contiguous().clone()
+        if i < len(self._store):
+            self._store[i] = value
+        else:
+            self._store.append(value)
+        return value
+
+    def _gemm(self, w_tkc: torch.Tensor, bias: torch.Tensor, act: int, **kw: Any) -> _GemmLayer:
+        taps, cin, cout = w_tkc.shape
+        cout8 = (cout + 7) // 8 * 8
+        packed, nb = pack_gemm_weights(w_tkc, self.device)
+        b = torch.zeros(nb * 128, dtype=torch.float32, device=self.device)
+        b[:cout] = bias.to(self.device)
+        for k in ("ln_g", "ln_b", "post_add"):
+            if kw.get(k) is not None:
+                kw[k] = self._put(kw[k])
+        return _GemmLayer(self._put(packed), self._put(b), cin, cout8, taps, act, nb, **kw)
+
+    def _conv_layer(self, conv: nn.Conv2d, bn: nn.Module | None, act: int, **kw: Any) -> _GemmLayer:
+        w, b = _fold_bn(conv.weight, conv.bias, bn)  # [Cout, Cin, kh, kw]
+        cout, cin, kh, kw_ = w.shape
+        w_tkc = w.permute(2, 3, 1, 0).reshape(kh * kw_, cin, cout)
+        return self._gemm(w_tkc, b, act, **kw)
+
+    def _linear_layer(self, lin: nn.Linear, bn: nn.Module | None, act: int, **kw: Any) -> _GemmLayer:
+        w, b = _fold_bn(lin.weight, lin.bias, bn)  # [N, K]
+        return self._gemm(w.t().unsqueeze(0).contiguous(), b, act, **kw)
+
+    @torch.no_grad()
+    def load_from_module(self, model: nn.Module) -> None:
+        mc, dev = self.mc, self.device
+        D = mc.TRANSFORMER_DIM
+        self._store_cursor = 0
+        # ---- conv stem
+        stem = [(_split_seq(blk)[0]) for blk in model.conv_body]
+        conv0, bn0, _ = stem[0]
+        w0, b0 = _fold_bn(conv0.weight, conv0.bias, bn0)  # [C0, 1, 3, 3]
+        self.c0 = w0.shape[0]
+        self.w_first = self._put(w0.reshape(self.c0, 9).t().contiguous())  # [9][C0]
+        self.b_first = self._put(b0)
+        self.body_layers: list[tuple[str, _GemmLayer]] = []
+        for conv, bn, _ in stem[1:]:
+            self.body_layers.append(("plain", self._conv_layer(conv, bn, self.act)))
+        # ---- residual body
+        for blk in model.res_body:
+            if isinstance(blk, nn.Sequential):
+                conv, bn, _ = _split_seq(blk)[0]
+                self.body_layers.append(("plain", self._conv_layer(conv, bn, self.act)))
+            else:
+                c1, bn1, _ = _split_seq(blk.conv1)[0]
+                self.body_layers.append(("res_a", self._conv_layer(c1, bn1, self.act)))
+                self.body_layers.append(("res_b", self._conv_layer(blk.conv2, blk.bn2, self.act)))
+        self.body_channels = self.body_layers[-1][1].cout if self.body_layers else self.c0
+        # ---- transformer
+        self.tf_layers: list[dict[str, Any]] = []
+        self.proj: _GemmLayer | None = None
+        self.final_ln: tuple[torch.Tensor, torch.Tensor, float] | None = None
+        if self.uses_tf:
+            pe = model.pos_encoder.pe[: self.HW, 0, :].detach().float().contiguous().to(dev)
+            if isinstance(model.input_proj, nn.Conv2d):
+                self.proj = self._conv_layer(model.input_proj, None, 0, post_add=pe)
+            elif self.body_layers:
+                self.body_layers[-1][1].post_add = self._put(pe)
+            else:
+                raise ValueError("transformer directly on the first conv layer is not supported")
+            hd = D // mc.TRANSFORMER_HEADS
+            for layer in model.transformer_body.layers:
+                w_in = layer.self_attn.in_proj_weight.detach().float().clone()  # [3D, D]
+                b_in = layer.self_attn.in_proj_bias.detach().float().clone()
+                w_in[:D] *= 1.0 / math.sqrt(hd)
+                b_in[:D] *= 1.0 / math.sqrt(hd)
+                qkv = self._gemm(
+                    w_in.t().unsqueeze(0).contiguous(), b_in, 0,
+                    ln_g=layer.norm1.weight.detach().float().to(dev), ln_b=layer.norm1.bias.detach().float().to(dev),
+                    ln_eps=float(layer.norm1.eps),
+                )
+                out = self._linear_layer(layer.self_attn.out_proj, None, 0)
+                ff1 = self._linear_layer(
+                    layer.linear1, None, self.act,
+                    ln_g=layer.norm2.weight.detach().float().to(dev), ln_b=layer.norm2.bias.detach().float().to(dev),
+                    ln_eps=float(layer.norm2.eps),
+                )
+                ff2 = self._linear_layer(layer.linear2, None, 0)
+                self.tf_layers.append({"qkv": qkv, "out": out, "ff1": ff1, "ff2": ff2})
+            fn = model.transformer_body.norm
+            self.final_ln = (self._put(fn.weight.detach().float()), self._put(fn.bias.detach().float()), float(fn.eps))
+            self.feat_c = D
+        else:
+            self.feat_c = self.body_channels
+        # ---- shared FC (first layer split-K, the rest dense)
+        shared = _split_seq(model.shared_fc)
+        lin0, bnf, _ = shared[0]
+        w, b = _fold_bn(lin0.weight, lin0.bias, bnf)  # [N, feat + other]
+        feat = self.HW * self.feat_c
+        wf = w[:, :feat]
+        if not self.uses_tf:  # PyTorch flattens NCHW (c*HW + p); activations here are NHWC (p*C + c)
+            wf = wf.reshape(-1, self.feat_c, self.HW).permute(0, 2, 1).reshape(-1, feat)
+        wo = torch.zeros(w.shape[0], self.other_pad, device=w.device)
+        wo[:, : self.other_dim] = w[:, feat : feat + self.other_dim]
+        wk = torch.cat([wf, wo], dim=1).t().contiguous()  # [Kp, N]
+        self.fc_kp = wk.shape[0]
+        self.fc_n = wk.shape[1]
+        self.fc_w = self._put(pack_gemm_weights(wk.unsqueeze(0), dev)[0])
+        self.fc_b = self._put(b)
+        self.shared_rest = [self._linear_layer(l, bn, self.act if a else 0) for l, bn, a in shared[1:]]
+        self.policy_layers = [self._linear_layer(l, bn, self.act if a else 0) for l, bn, a in _split_seq(model.policy_head)]
+        self.value_layers = [self._linear_layer(l, bn, self.act if a else 0) for l, bn, a in _split_seq(model.value_head)]
+        total_steps = self.fc_kp // 32
+        self.fc_sk = max(1, min(16, total_steps // 16))
+        self.loaded = True
+
+    # ------------------------------------------------------------------ buffers
+    def reserve(self, batch: int) -> None:
+        """Allocate activation / output buffers for up to ``batch`` samples (pointers stay stable until it grows)."""
+        if batch <= self.cap:
+            return
+        dev = self.device
+        rows = batch * self.HW
+        widths = [self.c0, self.body_channels, self.feat_c]
+        for _, l in self.body_layers:
+            widths.append(l.cout)
+        if self.uses_tf:
+            widths += [3 * self.mc.TRANSFORMER_DIM, self.mc.TRANSFORMER_FC_DIM]
+        maxc = max(widths)
+        self.bufs = [torch.empty(rows * maxc, dtype=torch.bfloat16, device=dev) for _ in range(5)]
+        self.fc_in = torch.zeros(batch, self.fc_kp, dtype=torch.bfloat16, device=dev)
+        self.slabs = torch.empty(self.fc_sk, batch, 128, dtype=torch.float32, device=dev)
+        dense_w = max([self.fc_n] + [l.cout for l in self.shared_rest + self.policy_layers + self.value_layers])
+        self.dense = [torch.empty(batch * dense_w, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+        self.logits = torch.zeros(batch, self.logit_stride, dtype=torch.float32, device=dev)
+        self.vlogits = torch.zeros(batch, self.value_stride, dtype=torch.float32, device=dev)
+        self.values = torch.zeros(batch, dtype=torch.float32, device=dev)
+        self.cap = batch
+
+    # ------------------------------------------------------------------ launches
+    def _run_gemm(self, layer: _GemmLayer, src: torch.Tensor, dst: torch.Tensor, rows: int, *, conv: bool,
+                  residual: torch.Tensor | None = None, out_f32: bool = False, out_stride: int | None = None) -> None:
+        if conv:
+            hw, h, w, rpw = self.HW, self.H, self.W, self.rows_per_wg
+        else:
+            hw, h, w, rpw = 1, 1, 1, 240
+        hb.call(
+            "atri_tile_gemm",
+            hb.ptr(src), hb.ptr(layer.w), hb.ptr(layer.bias), hb.ptr(residual), hb.ptr(layer.post_add),
+            hb.ptr(layer.ln_g), hb.ptr(layer.ln_b), hb.ptr(dst),
+            hb.i32(rows), hb.i32(rpw), hb.i32(hw), hb.i32(h), hb.i32(w), hb.i32(layer.cin), hb.i32(layer.cout),
+            hb.i32(layer.taps), hb.i32(layer.act), hb.i32(1 if out_f32 else 0),
+            hb.i32(out_stride if out_stride is not None else layer.cout), hb.i32(layer.n_blocks), hb.f32(layer.ln_eps),
+        )
+
+    @torch.no_grad()
+    def forward(self, grid: torch.Tensor, other: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """``grid`` f32 [B, 1, H, W] (or [B, HW]), ``other`` f32 [B, Do] -> ``(logits [B, A], value [B])``.
+
+        The returned tensors are views of the engine's persistent output buffers.
+        """
+        if not self.loaded:
+            raise RuntimeError("InferenceEngine.load_from_module has not been called")
+        B = int(grid.shape[0])
+        if B == 0:
+            return torch.empty(0, self.A, device=self.device), torch.empty(0, device=self.device)
+        self.reserve(B)
+        if grid.dtype != torch.float32 or not grid.is_contiguous():
+            grid = grid.float().contiguous()
+        if other.dtype != torch.float32 or not other.is_contiguous():
+            other = other.float().contiguous()
+        if grid.numel() != B * self.HW or other.numel() != B * self.other_dim:
+            raise ValueError("feature tensor shapes do not match the engine configuration")
+        rows = B * self.HW
+        bufs = self.bufs
+        hb.call("atri_conv_first", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.ptr(bufs[0]),
+                hb.i32(rows), hb.i32(self.HW), hb.i32(self.H), hb.i32(self.W), hb.i32(self.c0), hb.i32(self.act))
+        cur = 0  # index of the buffer holding the current activation
+        for kind, layer in self.body_layers:
+            if kind in ("plain", "res_a"):
+                dst = (cur + 1) % 3
+                self._run_gemm(layer, bufs[cur], bufs[dst], rows, conv=True)
+                if kind == "res_a":
+                    res_in, cur = cur, dst
+                else:
+                    cur = dst
+            else:  # res_b: second conv of a residual block, skip connection from the block input
+                dst = 3 - cur - res_in  # the third of buffers {0,1,2}
+                self._run_gemm(layer, bufs[cur], bufs[dst], rows, conv=True, residual=bufs[res_in])
+                cur = dst
+        if self.uses_tf:
+            if self.proj is not None:
+                dst = (cur + 1) % 3
+                self._run_gemm(self.proj, bufs[cur], bufs[dst], rows, conv=True)
+                cur = dst
+            D, heads = self.mc.TRANSFORMER_DIM, self.mc.TRANSFORMER_HEADS
+            x = cur
+            for tl in self.tf_layers:
+                free = [i for i in range(5) if i != x]
+                q, t, y, h = free[0], free[1], free[2], free[3]
+                self._run_gemm(tl["qkv"], bufs[x], bufs[q], rows, conv=True)
+                hb.call("atri_attention", hb.ptr(bufs[q]), hb.ptr(bufs[t]), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads))
+                self._run_gemm(tl["out"], bufs[t], bufs[y], rows, conv=True, residual=bufs[x])
+                self._run_gemm(tl["ff1"], bufs[y], bufs[h], rows, conv=True)
+                self._run_gemm(tl["ff2"], bufs[h], bufs[q], rows, conv=True, residual=bufs[y])
+                x = q
+            cur = x
+            g, bt, eps = self.final_ln  # type: ignore[misc]
+            hb.call("atri_rows_to_fc", hb.ptr(bufs[cur]), hb.ptr(g), hb.ptr(bt), hb.ptr(self.fc_in), hb.i32(rows),
+                    hb.i32(self.HW), hb.i32(self.feat_c), hb.i32(self.fc_kp), hb.f32(eps))
+        else:
+            hb.call("atri_rows_to_fc", hb.ptr(bufs[cur]), hb.ptr(None), hb.ptr(None), hb.ptr(self.fc_in), hb.i32(rows),
+                    hb.i32(self.HW), hb.i32(self.feat_c), hb.i32(self.fc_kp), hb.f32(0.0))
+        hb.call("atri_other_to_fc", hb.ptr(other), hb.ptr(self.fc_in), hb.i32(B), hb.i32(self.other_dim),
+                hb.i32(self.other_pad), hb.i32(self.fc_kp), hb.i32(self.HW * self.feat_c))
+        hb.call("atri_fc_splitk", hb.ptr(self.fc_in), hb.ptr(self.fc_w), hb.ptr(self.slabs), hb.i32(B), hb.i32(self.fc_kp),
+                hb.i32(self.fc_n), hb.i32(self.fc_sk))
+        # slabs are laid out [SK][cap][128]; the kernel indexes them with the live batch size
+        hb.call("atri_fc_finish", hb.ptr(self.slabs), hb.ptr(self.fc_b), hb.ptr(self.dense[0]), hb.i32(B), hb.i32(self.fc_n),
+                hb.i32(self.fc_sk), hb.i32(self.act))
+        d = 0
+        for layer in self.shared_rest:
+            self._run_gemm(layer, self.dense[d], self.dense[1 - d], B, conv=False)
+            d = 1 - d
+        shared = d
+        src = shared
+        for i, layer in enumerate(self.policy_layers):
+            last = i == len(self.policy_layers) - 1
+            if last:
+                self._run_gemm(layer, self.dense[src], self.logits, B, conv=False, out_f32=True, out_stride=self.logit_stride)
+            else:
+                dst = 2 if src == shared else (1 - shared if src == 2 else 2)
+                self._run_gemm(layer, self.dense[src], self.dense[dst], B, conv=False)
+                src = dst
+        src = shared
+        for i, layer in enumerate(self.value_layers):
+            last = i == len(self.value_layers) - 1
+            if last:
+                self._run_gemm(layer, self.dense[src], self.vlogits, B, conv=False, out_f32=True, out_stride=self.value_stride)
+            else:
+                dst = 2 if src == shared else (1 - shared if src == 2 else 2)
+                self._run_gemm(layer, self.dense[src], self.dense[dst], B, conv=False)
+                src = dst
+        dz = (self.mc.VALUE_MAX - self.mc.VALUE_MIN) / (self.mc.NUM_VALUE_ATOMS - 1)
+        hb.call("atri_c51_expect", hb.ptr(self.vlogits), hb.i32(self.value_stride), hb.i32(self.mc.NUM_VALUE_ATOMS),
+                hb.f32(self.mc.VALUE_MIN), hb.f32(dz), hb.ptr(self.values), hb.i32(B))
+        return self.logits[:B, : self.A], self.values[:B]

@@ -1,0 +1,197 @@
+"""GPU-resident self-play actor: thousands of games, trees and the network on one MI355X.
+
+Replaces a whole pool of the reference's Ray CPU workers
+(alphatriangle/rl/self_play/worker.py:35-599 + alphatriangle/training/worker_manager.py):
+one ``play_move`` call advances every game by one move - root evaluation, Dirichlet
+noise, ``max_simulations`` simulation waves (tree kernel -> network forward over all
+leaves), policy target + action sampling, n-step bookkeeping, experience emission into
+the HBM replay, re-rooting with subtree reuse.  The steady-state wave
+(tree kernel + ~25 network kernels) is captured once into a HIP graph and replayed.
+"""
+
+from __future__ import annotations
+
+import logging
+import time
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+import torch
+
+from ...config.env_config import EnvConfig
+from ...config.mcts_config import AlphaTriangleMCTSConfig
+from ...config.model_config import ModelConfig
+from ...config.system_config import SystemConfig
+from ...config.train_config import TrainConfig
+from ...models.network import NeuralNetwork
+from ...ops.engine import GpuTreeEngine
+from ...rl.core.device_buffer import DeviceReplayBuffer
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class GpuMoveReport:
+    """What one ``play_move`` call produced (all games advanced by one move)."""
+
+    moves: int
+    simulations: int
+    experiences_added: int
+    episodes_finished: int
+    episode_contexts: list[dict[str, float]] = field(default_factory=list)
+    mean_step_reward: float = 0.0
+    triangles_cleared: int = 0
+    trainer_step: int = 0
+    seconds: float = 0.0
+
+
+class GpuSelfPlayActor:
+    def __init__(
+        self,
+        env_config: EnvConfig,
+        model_config: ModelConfig,
+        mcts_config: AlphaTriangleMCTSConfig,
+        train_config: TrainConfig,
+        system_config: SystemConfig,
+        nn: NeuralNetwork,
+        replay: DeviceReplayBuffer,
+        device: torch.device,
+        seed: int = 0,
+    ):
+        if nn.engine is None:
+            raise RuntimeError(
+                "GpuSelfPlayActor needs the HIP inference engine (unsupported model config or missing libatri_hip.so)"
+            )
+        self.env_config = env_config
+        self.mcts_config = mcts_config
+        self.train_config = train_config
+        self.system_config = system_config
+        self.nn = nn
+        self.replay = replay
+        self.device = torch.device(device)
+        self.G = int(system_config.GAMES_PER_GPU)
+        self.L = int(system_config.LEAVES_PER_TREE)
+        self.B = self.G * self.L
+        self.engine = nn.engine
+        self.engine.reserve(self.B)
+        self.tree = GpuTreeEngine(
+            env_config, mcts_config, self.device, self.G, self.L, model_config.OTHER_NN_INPUT_FEATURES_DIM,
+            self.engine.logits, self.engine.values, seed=seed,
+        )
+        if system_config.TEMPERATURE_SWITCH_GAME_STEP is not None:
+            switch = int(system_config.TEMPERATURE_SWITCH_GAME_STEP)
+        elif train_config.MAX_TRAINING_STEPS is not None:
+            switch = int(train_config.MAX_TRAINING_STEPS * 0.1)  # the reference's rule
+        else:
+            switch = 2**31 - 1
+        if replay.emit_capacity < self.G * (train_config.N_STEP_RETURNS + 1):
+            raise ValueError("DeviceReplayBuffer.emit_capacity is too small for this many games")
+        self.tree.attach_replay(
+            replay, train_config.N_STEP_RETURNS, train_config.GAMMA, base_seed=seed, temp_switch_step=switch,
+            tree_reuse=system_config.TREE_REUSE,
+        )
+        self.waves_per_move = (mcts_config.max_simulations + self.L - 1) // self.L
+        seeds = np.random.default_rng(seed).integers(1, 2**63 - 1, size=self.G, dtype=np.int64).astype(np.uint64)
+        self.tree.reset_games(seeds)
+        self.current_trainer_step = 0
+        self.total_moves = 0
+        self.total_episodes = 0
+        self._ep_seen = 0
+        self._graph: torch.cuda.CUDAGraph | None = None
+        self._use_graph = bool(system_config.USE_HIP_GRAPHS)
+        self._grid_view = self.tree.nn_grid
+        self._other_view = self.tree.nn_other
+        logger.info(
+            "GPU self-play actor: %d games, %d leaves/tree, %d sims/move -> network batch %d, %d waves/move",
+            self.G, self.L, mcts_config.max_simulations, self.B, self.waves_per_move,
+        )
+
+    # ------------------------------------------------------------------ weights
+    def sync_weights(self, trainer_step: int) -> None:
+        """Re-fold + re-pack the learner's current parameters into the inference engine (in place)."""
+        self.nn.sync_inference_weights()
+        self.current_trainer_step = int(trainer_step)
+
+    # ------------------------------------------------------------------ one simulation wave
+    def _forward(self) -> None:
+        self.engine.forward(self._grid_view, self._other_view)
+
+    def _steady_wave(self) -> None:
+        self.tree.wave(consume=True, select=True)
+        self._forward()
+
+    def _capture(self) -> None:
+        """Capture the steady-state wave into a HIP graph.
+
+        Every kernel in it has already run eagerly (root evaluation + first wave of this move),
+        and the wave allocates nothing, so capture needs no separate warm-up.
+        """
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._steady_wave()
+        self._graph = g
+
+    @torch.no_grad()
+    def play_move(self) -> GpuMoveReport:
+        t0 = time.perf_counter()
+        tree = self.tree
+        tree.move_stats.zero_()
+        tree.prepare_roots()
+        self._forward()
+        tree.init_roots()
+        waves = self.waves_per_move
+        tree.wave(consume=False, select=True)
+        self._forward()
+        remaining = waves - 1
+        if remaining > 0:
+            if self._use_graph:
+                if self._graph is None:
+                    self._capture()  # capture executes nothing; the replays below do the work
+                assert self._graph is not None
+                for _ in range(remaining):
+                    self._graph.replay()
+            else:
+                for _ in range(remaining):
+                    self._steady_wave()
+        tree.wave(consume=True, select=False)
+        self.replay.begin_commit()
+        tree.commit_moves()
+        tree.reroot()
+        added = self.replay.end_commit()
+        stats = tree.move_stats.cpu().numpy()
+        ep_total = int(tree.ep_count.item())
+        new_eps = ep_total - self._ep_seen
+        contexts: list[dict[str, float]] = []
+        if new_eps > 0:
+            take = min(new_eps, tree.ep_ring)
+            idx = (torch.arange(ep_total - take, ep_total, device=self.device) % tree.ep_ring).long()
+            score = tree.ep_score[idx].cpu().numpy()
+            length = tree.ep_len[idx].cpu().numpy()
+            sims = tree.ep_sims_out[idx].cpu().numpy()
+            cleared = tree.ep_cleared[idx].cpu().numpy()
+            for i in range(take):
+                contexts.append({"score": float(score[i]), "length": int(length[i]), "simulations": int(sims[i]), "triangles_cleared": int(cleared[i])})
+            self._ep_seen = ep_total
+        moves = int(stats[2])
+        self.total_moves += moves
+        self.total_episodes += new_eps
+        return GpuMoveReport(
+            moves=moves,
+            simulations=int(stats[4]),
+            experiences_added=added,
+            episodes_finished=new_eps,
+            episode_contexts=contexts,
+            mean_step_reward=float(stats[0] / max(moves, 1)),
+            triangles_cleared=int(stats[1]),
+            trainer_step=self.current_trainer_step,
+            seconds=time.perf_counter() - t0,
+        )
+
+    # ------------------------------------------------------------------ checkpointing of the actor state
+    def state_dict(self) -> dict[str, Any]:
+        return {"total_moves": self.total_moves, "total_episodes": self.total_episodes}
+
+    def load_state(self, state: dict[str, Any]) -> None:
+        self.total_moves = int(state.get("total_moves", 0))
+        self.total_episodes = int(state.get("total_episodes", 0))

@@ -1,0 +1,188 @@
+"""HIP game / tree engine vs the host C++ engine (bit-exact by construction; needs an MI355X)."""
+
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from alphatriangle_amd import native
+from alphatriangle_amd.config import AlphaTriangleMCTSConfig, EnvConfig, ModelConfig, SystemConfig, TrainConfig
+from alphatriangle_amd.env import GameState
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(env, mcts, games, leaves, other_dim=30):
+    from alphatriangle_amd.ops.engine import GpuTreeEngine
+
+    dev = torch.device("cuda")
+    logits = torch.zeros(games * leaves, env.ACTION_DIM, dtype=torch.float32, device=dev)
+    values = torch.zeros(games * leaves, dtype=torch.float32, device=dev)
+    return GpuTreeEngine(env, mcts, dev, games, leaves, other_dim, logits, values, seed=1)
+
+
+def _packed(states):
+    return torch.from_numpy(np.stack([np.frombuffer(s.core.pack(), dtype=np.uint8) for s in states]).copy())
+
+
+@pytest.mark.parametrize("env", [EnvConfig(), EnvConfig(ROWS=5, COLS=6, PLAYABLE_RANGE_PER_ROW=[(0, 6)] * 5, NUM_SHAPE_SLOTS=2), EnvConfig.large()])
+def test_step_valid_features_bit_exact(env):
+    rng = random.Random(5)
+    other_dim = 8 * env.NUM_SHAPE_SLOTS + 6
+    eng = _engine(env, AlphaTriangleMCTSConfig(max_simulations=4), 1, 1, other_dim)
+    H = native.host()
+    before, actions, after, rewards, dones = [], [], [], [], []
+    for seed in range(6):
+        g = GameState(env, initial_seed=seed)
+        while not g.is_over() and len(before) < 400:
+            a = rng.choice(g.valid_actions())
+            before.append(g.copy())
+            r, d = g.step(a)
+            actions.append(a)
+            after.append(g.copy())
+            rewards.append(r)
+            dones.append(d)
+    n = len(before)
+    st = _packed(before).cuda()
+    # valid masks and features of the pre-move states
+    mask = eng.valid_mask(st).cpu().numpy().astype(bool)
+    grid, other = eng.features(st)
+    for i in range(n):
+        assert np.array_equal(mask[i], before[i].valid_mask())
+    hg, ho = H.extract_features_batch([s.core for s in before], 1, other_dim, env.ROWS, env.COLS)
+    assert np.array_equal(grid.cpu().numpy(), hg.reshape(n, -1))
+    assert np.array_equal(other.cpu().numpy(), ho)
+    # stepping
+    rew, done = eng.step_states(st, torch.tensor(actions, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    assert np.array_equal(st.cpu().numpy(), _packed(after).numpy())
+    assert np.array_equal(rew.cpu().numpy(), np.asarray(rewards, dtype=np.float32))
+    assert np.array_equal(done.cpu().numpy().astype(bool), np.asarray(dones))
+
+
+class _SyntheticNet:
+    """Deterministic stand-in network evaluated on the CPU in float64, shared by both searches."""
+
+    def __init__(self, cells, other_dim, action_dim):
+        rng = np.random.default_rng(11)
+        self.w1 = rng.normal(size=(cells, 8))
+        self.w2 = rng.normal(size=(other_dim, 8))
+        self.w3 = rng.normal(size=(8, action_dim))
+        self.w4 = rng.normal(size=8)
+
+    def __call__(self, grid, other):
+        h = np.tanh(grid.reshape(grid.shape[0], -1).astype(np.float64) @ self.w1 * 0.1 + other.astype(np.float64) @ self.w2)
+        logits = np.round(h @ self.w3 * 64.0) / 64.0
+        values = np.round(np.tanh(h @ self.w4) * 3.0 * 256.0) / 256.0
+        return logits.astype(np.float32), values.astype(np.float32)
+
+
+@pytest.mark.parametrize("leaves", [1, 3])
+def test_tree_search_equals_host_search(leaves):
+    env = EnvConfig()
+    sims = 48
+    mcts = AlphaTriangleMCTSConfig(max_simulations=sims, max_depth=6, dirichlet_epsilon=0.0, mcts_batch_size=leaves)
+    G = 6
+    eng = _engine(env, mcts, G, leaves)
+    net = _SyntheticNet(env.ROWS * env.COLS, 30, env.ACTION_DIM)
+    H = native.host()
+    games = []
+    rng = random.Random(3)
+    for i in range(G):
+        g = GameState(env, initial_seed=100 + i)
+        for _ in range(i * 2):  # different depths into the game
+            if g.is_over():
+                break
+            g.step(rng.choice(g.valid_actions()))
+        games.append(g)
+
+    def device_eval():
+        lg, vl = net(eng.nn_grid.cpu().numpy(), eng.nn_other.cpu().numpy())
+        eng.logits.copy_(torch.from_numpy(lg).cuda())
+        eng.values.copy_(torch.from_numpy(vl).cuda())
+
+    eng.set_roots(_packed(games).cuda())
+    eng.prepare_roots()
+    device_eval()
+    eng.init_roots()
+    waves = (sims + leaves - 1) // leaves
+    for w in range(waves):
+        eng.wave(consume=w > 0, select=True)
+        device_eval()
+    eng.wave(consume=True, select=False)
+    dv = eng.root_visits().cpu().numpy()
+    torch.cuda.synchronize()
+
+    def host_eval(core_states):
+        hg, ho = H.extract_features_batch(core_states, 1, 30, env.ROWS, env.COLS)
+        return net(hg, ho)
+
+    params = mcts.to_search_params(leaf_batch=leaves)
+    # the device runs `waves` full waves; give the host the same simulation budget
+    params.max_simulations = waves * leaves
+    for i, g in enumerate(games):
+        tree = H.SearchTree(g.geometry, mcts.capacity(), 0)
+        hv = tree.search(g.core, params, host_eval, -1)
+        assert np.array_equal(hv, dv[i]), f"game {i}: host {np.nonzero(hv)[0][:8]} vs device {np.nonzero(dv[i])[0][:8]}"
+        assert hv.sum() > 0
+
+
+def _actor(games=48, sims=12, graphs=True, leaves=1, seed=7):
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.rl.core.device_buffer import DeviceReplayBuffer
+    from alphatriangle_amd.rl.self_play.gpu_actor import GpuSelfPlayActor
+
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    env, mc = EnvConfig(), ModelConfig()
+    tc = TrainConfig(DEVICE="cuda", BUFFER_CAPACITY=20000, MIN_BUFFER_SIZE_TO_TRAIN=64, BATCH_SIZE=32, N_STEP_RETURNS=3, MAX_TRAINING_STEPS=1000)
+    sc = SystemConfig(GAMES_PER_GPU=games, LEAVES_PER_TREE=leaves, USE_HIP_GRAPHS=graphs)
+    mcts = AlphaTriangleMCTSConfig(max_simulations=sims, max_depth=5)
+    net = NeuralNetwork(mc, env, tc, dev)
+    replay = DeviceReplayBuffer(tc, env, mc, dev, sc)
+    actor = GpuSelfPlayActor(env, mc, mcts, tc, sc, net, replay, dev, seed=seed)
+    return actor, replay, tc
+
+
+def test_play_move_invariants_and_replay_flow():
+    actor, replay, tc = _actor()
+    G = actor.G
+    total_added = 0
+    for move in range(6):
+        rep = actor.play_move()
+        assert rep.moves == G
+        assert rep.simulations >= G * 12
+        total_added += rep.experiences_added
+        assert len(replay) == total_added
+        assert (actor.tree.n_nodes <= actor.tree.C).all()
+    # with 3-step returns the first experiences appear on the 4th move (or earlier when games end)
+    assert total_added >= G * 2
+    n = len(replay)
+    pol = replay.policy[:n]
+    assert torch.allclose(pol.sum(1), torch.ones(n, device=pol.device), atol=1e-4)
+    assert torch.isfinite(replay.ret[:n]).all()
+    assert abs(replay.total_priority() - n * 1.0) < 1e-6  # every new leaf at max priority 1.0
+    batch = replay.sample(32, current_train_step=0)
+    assert batch is not None and batch.grid.shape == (32, 1, 8, 15) and batch.policy_target.shape == (32, 360)
+    assert (batch.indices >= 0).all() and (batch.indices < n).all()
+    assert ((batch.weights > 0) & (batch.weights <= 1.0 + 1e-6)).all()
+
+
+def test_graph_replay_equals_eager():
+    """The captured wave graph is replayed many times per move; its searches must equal eager ones."""
+    a1, r1, _ = _actor(graphs=True)
+    a2, r2, _ = _actor(graphs=False)
+    for _ in range(4):
+        a1.play_move()
+        a2.play_move()
+        torch.cuda.synchronize()
+        assert torch.equal(a1.tree.chosen_action, a2.tree.chosen_action)
+        assert torch.equal(a1.tree.n_nodes, a2.tree.n_nodes)
+    assert len(r1) == len(r2)
+    n = len(r1)
+    if n:
+        assert torch.equal(r1.policy[:n], r2.policy[:n])
+        assert torch.equal(r1.ret[:n], r2.ret[:n])

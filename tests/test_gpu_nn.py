@@ -1,0 +1,157 @@
+"""HIP inference kernels vs plain PyTorch fp32 references (needs an MI355X)."""
+
+from __future__ import annotations
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from alphatriangle_amd.config import EnvConfig, ModelConfig, TrainConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda")
+
+
+def _bf16_round(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).float()
+
+
+def test_library_loads_and_abi_matches():
+    from alphatriangle_amd.ops import hipbind as hb
+
+    assert hb.lib() is not None
+
+
+@pytest.mark.parametrize("cin,cout,taps,residual,act", [(32, 64, 9, False, 1), (128, 128, 9, True, 1), (128, 384, 1, False, 0), (256, 128, 1, True, 2)])
+def test_tile_gemm_matches_torch(cin, cout, taps, residual, act):
+    from alphatriangle_amd.ops import hipbind as hb
+    from alphatriangle_amd.ops.inference import pack_gemm_weights
+
+    torch.manual_seed(0)
+    dev = _dev()
+    B, H, W = 5, 8, 15
+    HW = H * W
+    x = _bf16_round(torch.randn(B, HW, cin, device=dev))
+    k = 3 if taps == 9 else 1
+    w = _bf16_round(torch.randn(cout, cin, k, k, device=dev) * (1.0 / math.sqrt(cin * taps)))
+    bias = torch.randn(cout, device=dev)
+    res = _bf16_round(torch.randn(B, HW, cout, device=dev)) if residual else None
+    post = torch.randn(HW, cout, device=dev)
+    # reference in fp32, NCHW
+    xn = x.view(B, H, W, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xn, w, bias, padding=k // 2).permute(0, 2, 3, 1).reshape(B, HW, cout)
+    if res is not None:
+        ref = ref + res
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    ref = ref + post[None]
+    packed, nb = pack_gemm_weights(w.permute(2, 3, 1, 0).reshape(taps, cin, cout), dev)
+    bpad = torch.zeros(nb * 128, device=dev)
+    bpad[:cout] = bias
+    out = torch.zeros(B * HW, cout, dtype=torch.bfloat16, device=dev)
+    xb = x.to(torch.bfloat16).contiguous()
+    rb = res.to(torch.bfloat16).contiguous() if res is not None else None
+    hb.call(
+        "atri_tile_gemm", hb.ptr(xb), hb.ptr(packed), hb.ptr(bpad), hb.ptr(rb), hb.ptr(post), hb.ptr(None), hb.ptr(None), hb.ptr(out),
+        hb.i32(B * HW), hb.i32(240), hb.i32(HW), hb.i32(H), hb.i32(W), hb.i32(cin), hb.i32(cout), hb.i32(taps), hb.i32(act), hb.i32(0),
+        hb.i32(cout), hb.i32(nb), hb.f32(1e-5),
+    )
+    torch.cuda.synchronize()
+    got = out.float().view(B, HW, cout)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 0.02 * scale + 0.02, f"max err {err} (scale {scale})"
+
+
+def test_tile_gemm_layernorm_prologue():
+    from alphatriangle_amd.ops import hipbind as hb
+    from alphatriangle_amd.ops.inference import pack_gemm_weights
+
+    torch.manual_seed(1)
+    dev = _dev()
+    rows, cin, cout = 600, 128, 256
+    x = _bf16_round(torch.randn(rows, cin, device=dev) * 2 + 0.5)
+    g = torch.randn(cin, device=dev)
+    b = torch.randn(cin, device=dev)
+    w = _bf16_round(torch.randn(cin, cout, device=dev) / math.sqrt(cin))
+    bias = torch.randn(cout, device=dev)
+    ref = _bf16_round(F.layer_norm(x, (cin,), g, b, 1e-5)) @ w + bias
+    packed, nb = pack_gemm_weights(w.unsqueeze(0), dev)
+    bpad = torch.zeros(nb * 128, device=dev)
+    bpad[:cout] = bias
+    out = torch.zeros(rows, cout, dtype=torch.float32, device=dev)
+    hb.call(
+        "atri_tile_gemm", hb.ptr(x.to(torch.bfloat16).contiguous()), hb.ptr(packed), hb.ptr(bpad), hb.ptr(None), hb.ptr(None), hb.ptr(g), hb.ptr(b),
+        hb.ptr(out), hb.i32(rows), hb.i32(240), hb.i32(1), hb.i32(1), hb.i32(1), hb.i32(cin), hb.i32(cout), hb.i32(1), hb.i32(0), hb.i32(1),
+        hb.i32(cout), hb.i32(nb), hb.f32(1e-5),
+    )
+    torch.cuda.synchronize()
+    err = (out - ref).abs().max().item()
+    assert err < 0.05, f"max err {err}"
+
+
+def test_attention_matches_torch():
+    from alphatriangle_amd.ops import hipbind as hb
+
+    torch.manual_seed(2)
+    dev = _dev()
+    B, HW, D, heads = 7, 120, 128, 4
+    qkv = _bf16_round(torch.randn(B, HW, 3 * D, device=dev) * 0.7)
+    q, k, v = qkv.split(D, dim=2)
+
+    def sh(t):
+        return t.view(B, HW, heads, 32).permute(0, 2, 1, 3)
+
+    ref = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), scale=1.0).permute(0, 2, 1, 3).reshape(B, HW, D)
+    out = torch.zeros(B, HW, D, dtype=torch.bfloat16, device=dev)
+    hb.call("atri_attention", hb.ptr(qkv.to(torch.bfloat16).contiguous()), hb.ptr(out), hb.i32(B), hb.i32(HW), hb.i32(D), hb.i32(heads))
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs().max().item()
+    assert err < 0.03, f"max err {err}"
+
+
+@pytest.mark.parametrize("preset", ["default", "cnn"])
+def test_engine_forward_matches_pytorch_module(preset):
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(3)
+    dev = _dev()
+    env = EnvConfig()
+    mc = ModelConfig() if preset == "default" else ModelConfig.cnn_only()
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev)
+    assert net.engine is not None, "HIP engine must be active on the GPU box"
+    # non-trivial BatchNorm statistics so the folding is really tested
+    with torch.no_grad():
+        for m in net._orig_model.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    net.sync_inference_weights()
+    B = 37
+    grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    net._orig_model.eval()
+    with torch.no_grad():
+        ref_logits, ref_vlogits = net._orig_model(grid, other)
+        ref_value = net._logits_to_expected_value(ref_vlogits).squeeze(1)
+    logits, value = net.evaluate_features(grid, other)
+    torch.cuda.synchronize()
+    assert logits.shape == (B, env.ACTION_DIM)
+    assert torch.isfinite(logits).all() and torch.isfinite(value).all()
+    lerr = (logits - ref_logits).abs().max().item()
+    verr = (value - ref_value).abs().max().item()
+    lscale = ref_logits.abs().max().item()
+    assert lerr < 0.05 * max(lscale, 1.0) + 0.03, f"logit err {lerr} (scale {lscale})"
+    assert verr < 0.15, f"value err {verr}"
+    # policy agreement where it matters: same top action for nearly every sample
+    agree = (logits.argmax(1) == ref_logits.argmax(1)).float().mean().item()
+    assert agree > 0.8
