@@ -184,5 +184,12 @@ def test_graph_replay_equals_eager():
     assert len(r1) == len(r2)
     n = len(r1)
     if n:
-        assert torch.equal(r1.policy[:n], r2.policy[:n])
-        assert torch.equal(r1.ret[:n], r2.ret[:n])
+        # replay slots are handed out by an atomic counter, so the order across games is free:
+        # compare the experiences as multisets
+        key = torch.arange(1, r1.action_dim + 1, device=r1.device, dtype=torch.float64)
+
+        def signature(r):
+            h = (r.policy[:n].double() * key).sum(1) + 1000.0 * r.ret[:n].double() + r.grid[:n].double().sum(1) * 7.0
+            return torch.sort(h).values
+
+        assert torch.allclose(signature(r1), signature(r2), atol=0, rtol=0)
