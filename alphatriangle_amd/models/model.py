@@ -20,6 +20,40 @@ from ..config.env_config import EnvConfig
 from ..config.model_config import ModelConfig
 
 
+class GemmConv2d(nn.Conv2d):
+    """``nn.Conv2d`` (same parameters, same ``state_dict`` keys) whose GPU path is im2col + GEMM.
+
+    On gfx950 MIOpen has no tuned bf16 / fp32 convolution for these tiny 8x15 images and falls
+    back to naive kernels (11 ms for one weight-gradient call at batch 256).  Lowering the
+    convolution to ``unfold`` + one batched matmul puts forward, data-gradient and
+    weight-gradient on hipBLASLt GEMMs, which is what the learner needs.  CPU tensors keep the
+    stock implementation.
+    """
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if (
+            not x.is_cuda
+            or self.stride != (1, 1)
+            or self.dilation != (1, 1)
+            or self.groups != 1
+            or isinstance(self.padding, str)
+            or self.padding_mode != "zeros"
+        ):
+            return super().forward(x)
+        b, _, h, w = x.shape
+        kh, kw = self.kernel_size
+        ph, pw = self.padding
+        oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+        if kh == 1 and kw == 1 and ph == 0 and pw == 0:
+            cols = x.reshape(b, x.shape[1], h * w)
+        else:
+            cols = torch.nn.functional.unfold(x, (kh, kw), padding=(ph, pw))  # [B, Cin*kh*kw, oh*ow]
+        out = torch.matmul(self.weight.reshape(self.out_channels, -1), cols)  # [B, Cout, oh*ow]
+        if self.bias is not None:
+            out = out + self.bias.view(1, -1, 1)
+        return out.view(b, self.out_channels, oh, ow)
+
+
 def conv_block(
     in_channels: int,
     out_channels: int,
@@ -31,7 +65,7 @@ def conv_block(
 ) -> nn.Sequential:
     """Conv2d (bias only without BN) -> optional BatchNorm2d -> activation."""
     mods: list[nn.Module] = [
-        nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=not use_batch_norm)
+        GemmConv2d(in_channels, out_channels, kernel_size, stride, padding, bias=not use_batch_norm)
     ]
     if use_batch_norm:
         mods.append(nn.BatchNorm2d(out_channels))
@@ -45,7 +79,7 @@ class ResidualBlock(nn.Module):
     def __init__(self, channels: int, use_batch_norm: bool, activation: type[nn.Module]):
         super().__init__()
         self.conv1 = conv_block(channels, channels, 3, 1, 1, use_batch_norm, activation)
-        self.conv2 = nn.Conv2d(channels, channels, 3, 1, 1, bias=not use_batch_norm)
+        self.conv2 = GemmConv2d(channels, channels, 3, 1, 1, bias=not use_batch_norm)
         self.bn2 = nn.BatchNorm2d(channels) if use_batch_norm else nn.Identity()
         self.activation = activation()
 
@@ -141,7 +175,7 @@ class AlphaTriangleNet(nn.Module):
         if self.uses_transformer:
             d = mc.TRANSFORMER_DIM
             if channels != d:
-                self.input_proj = nn.Conv2d(channels, d, kernel_size=1)
+                self.input_proj = GemmConv2d(channels, d, kernel_size=1)
             self.pos_encoder = PositionalEncoding(d, dropout=0.1)
             layer = nn.TransformerEncoderLayer(
                 d_model=d,

@@ -36,7 +36,7 @@ def experience_is_valid(exp: Any) -> bool:
 class SelfPlayResult(BaseModel):
     model_config = ConfigDict(arbitrary_types_allowed=True)
 
-    episode_experiences: list[Experience]
+    episode_experiences: list[Any]
     final_score: float
     episode_steps: int
     trainer_step_at_episode_start: int

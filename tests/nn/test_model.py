@@ -1,0 +1,78 @@
+"""Network module (mirrors the reference's tests/nn/test_model.py: shapes, dtypes, transformer on/off)."""
+
+import pytest
+import torch
+
+from alphatriangle_amd.config import EnvConfig, ModelConfig
+from alphatriangle_amd.models import AlphaTriangleNet
+from alphatriangle_amd.models.model import GemmConv2d, PositionalEncoding, sinusoid_table
+
+
+def test_model_initialization(mock_model_config, mock_env_config, action_dim):
+    m = AlphaTriangleNet(mock_model_config, mock_env_config)
+    assert m.action_dim == action_dim == 9
+    assert m.model_config is mock_model_config and m.env_config is mock_env_config
+
+
+@pytest.mark.parametrize("batch_size", [1, 4])
+def test_forward_shapes(mock_model_config, mock_env_config, action_dim, batch_size):
+    m = AlphaTriangleNet(mock_model_config, mock_env_config).eval()
+    grid = torch.randn(batch_size, 1, 3, 3)
+    other = torch.randn(batch_size, mock_model_config.OTHER_NN_INPUT_FEATURES_DIM)
+    with torch.no_grad():
+        p, v = m(grid, other)
+    assert p.shape == (batch_size, action_dim) and v.shape == (batch_size, mock_model_config.NUM_VALUE_ATOMS)
+    assert p.dtype == torch.float32 and v.dtype == torch.float32
+
+
+@pytest.mark.parametrize("use_transformer", [False, True])
+def test_transformer_toggle(mock_env_config, use_transformer):
+    mc = ModelConfig(
+        CONV_FILTERS=[8], CONV_KERNEL_SIZES=[3], CONV_STRIDES=[1], CONV_PADDING=[1], NUM_RESIDUAL_BLOCKS=1, RESIDUAL_BLOCK_FILTERS=8,
+        USE_TRANSFORMER=use_transformer, TRANSFORMER_DIM=16, TRANSFORMER_HEADS=2, TRANSFORMER_LAYERS=1 if use_transformer else 0,
+        TRANSFORMER_FC_DIM=32, FC_DIMS_SHARED=[8], POLICY_HEAD_DIMS=[8], VALUE_HEAD_DIMS=[8], OTHER_NN_INPUT_FEATURES_DIM=14,
+    )
+    m = AlphaTriangleNet(mc, mock_env_config).eval()
+    assert (m.transformer_body is not None) == use_transformer
+    if use_transformer:
+        assert isinstance(m.input_proj, torch.nn.Conv2d)  # 8 -> 16 projection
+        assert m.transformer_output_size == 9 * 16
+    with torch.no_grad():
+        p, v = m(torch.randn(2, 1, 3, 3), torch.randn(2, 14))
+    assert p.shape == (2, 9) and v.shape == (2, 51)
+
+
+def test_default_net_size_and_state_dict_keys():
+    m = AlphaTriangleNet(ModelConfig(), EnvConfig())
+    assert sum(p.numel() for p in m.parameters()) == 3_005_819
+    keys = set(m.state_dict().keys())
+    for k in (
+        "conv_body.0.0.weight", "conv_body.2.1.running_var", "res_body.0.conv1.0.weight", "res_body.1.conv2.weight",
+        "res_body.1.bn2.bias", "pos_encoder.pe", "transformer_body.layers.0.self_attn.in_proj_weight",
+        "transformer_body.layers.1.linear2.bias", "transformer_body.layers.0.norm1.weight", "transformer_body.norm.weight",
+        "shared_fc.0.weight", "shared_fc.1.running_mean", "policy_head.3.weight", "value_head.3.bias",
+    ):
+        assert k in keys, k
+    assert m.state_dict()["pos_encoder.pe"].shape == (5000, 1, 128)
+    assert m.state_dict()["shared_fc.0.weight"].shape == (128, 15390)
+    assert isinstance(m.conv_body[0][0], GemmConv2d)
+
+
+def test_positional_encoding_validation():
+    pe = PositionalEncoding(8, dropout=0.0, max_len=10)
+    x = torch.zeros(4, 2, 8)
+    assert torch.allclose(pe(x)[:, 0], sinusoid_table(10, 8)[:4])
+    with pytest.raises(ValueError):
+        pe(torch.zeros(11, 1, 8))
+    with pytest.raises(ValueError):
+        pe(torch.zeros(4, 1, 6))
+    with pytest.raises(ValueError):
+        PositionalEncoding(0)
+
+
+def test_gemm_conv_lowering_equals_conv2d():
+    conv = GemmConv2d(3, 5, 3, 1, 1)
+    x = torch.randn(2, 3, 8, 15)
+    cols = torch.nn.functional.unfold(x, (3, 3), padding=(1, 1))
+    lowered = (conv.weight.reshape(5, -1) @ cols + conv.bias.view(1, -1, 1)).view(2, 5, 8, 15)
+    assert torch.allclose(lowered, conv(x), atol=1e-5)

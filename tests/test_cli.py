@@ -1,0 +1,52 @@
+import re
+
+from typer.testing import CliRunner
+
+from alphatriangle_amd.cli import app
+
+runner = CliRunner()
+
+
+def test_help_lists_reference_commands():
+    res = runner.invoke(app, ["--help"])
+    assert res.exit_code == 0
+    for cmd in ("train", "ml", "tb", "ray"):
+        assert cmd in res.output
+    res = runner.invoke(app, ["train", "--help"])
+    out = re.sub(r"\x1b\[[0-9;]*m", "", res.output)
+    for opt in ("--log-level", "--seed", "--profile", "--run-name"):
+        assert opt in out
+
+
+def test_ray_command_explains_replacement():
+    res = runner.invoke(app, ["ray"])
+    assert res.exit_code == 0 and "Ray" in res.output
+
+
+def test_ml_and_tb_fail_cleanly_without_tools(monkeypatch, tmp_path):
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr("alphatriangle_amd.cli.shutil.which", lambda _name: None)
+    for cmd in ("ml", "tb"):
+        res = runner.invoke(app, [cmd])
+        assert res.exit_code == 1 and "Could not find" in res.output
+
+
+def test_train_tiny_preset_through_cli(tmp_path):
+    res = runner.invoke(app, ["train", "--preset", "tiny", "--max-steps", "12", "--data-root", str(tmp_path), "--run-name", "cli", "--seed", "3", "--log-level", "WARNING"])
+    assert res.exit_code == 0, res.output
+    assert (tmp_path / "AlphaTriangle" / "runs" / "cli" / "checkpoints" / "latest.pkl").exists()
+
+
+def test_analyze_profiles(tmp_path):
+    import cProfile
+
+    import analyze_profiles
+
+    prof = cProfile.Profile()
+    prof.enable()
+    sum(range(1000))
+    prof.disable()
+    path = tmp_path / "w.prof"
+    prof.dump_stats(str(path))
+    res = CliRunner().invoke(analyze_profiles.app, [str(path), "-n", "5"])
+    assert res.exit_code == 0 and "Cumulative Time" in res.output

@@ -1,0 +1,138 @@
+"""Multi-process runtime on the gloo backend (CPU): collectives, data-parallel learner, role split."""
+
+from __future__ import annotations
+
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from alphatriangle_amd.config import EnvConfig, ModelConfig, TrainConfig
+from alphatriangle_amd.parallel.dist import RoleLayout, init_distributed
+from alphatriangle_amd.parallel.experience import ExperienceShipper, RecordLayout
+
+
+def _spawn(fn, world, *args):
+    with tempfile.TemporaryDirectory() as d:
+        init = f"file://{d}/store"
+        mp.spawn(fn, args=(world, init, *args), nprocs=world, join=True)
+
+
+def _collectives(rank, world, init):
+    torch.set_num_threads(1)
+    ctx = init_distributed(rank, world, rank, backend="gloo", init_method=init, timeout_s=60)
+    g = torch.full((10,), float(rank + 1))
+    ctx.grad_sync(g)
+    assert torch.allclose(g, torch.full((10,), 3.0))
+    w = torch.arange(6.0) if rank == 0 else torch.zeros(6)
+    ctx.broadcast_weights(w)
+    assert torch.equal(w, torch.arange(6.0))
+    blocks = ctx.all_gather_records(torch.full((2, 3), float(rank)))
+    assert blocks.shape == (2, 2, 3) and blocks[1].eq(1).all() and blocks[0].eq(0).all()
+    assert ctx.all_reduce_scalar(rank + 1.0, "max") == 2.0 and ctx.all_reduce_scalar(1.0, "sum") == 2.0
+    ctx.barrier()
+    ctx.shutdown()
+
+
+def test_collectives_two_ranks():
+    _spawn(_collectives, 2)
+
+
+def _tiny_cfg():
+    env = EnvConfig(ROWS=3, COLS=3, PLAYABLE_RANGE_PER_ROW=[(0, 3)] * 3, NUM_SHAPE_SLOTS=1)
+    mc = ModelConfig(CONV_FILTERS=[4], CONV_KERNEL_SIZES=[3], CONV_STRIDES=[1], CONV_PADDING=[1], NUM_RESIDUAL_BLOCKS=0,
+                     USE_TRANSFORMER=False, TRANSFORMER_LAYERS=0, FC_DIMS_SHARED=[8], POLICY_HEAD_DIMS=[8], VALUE_HEAD_DIMS=[8],
+                     OTHER_NN_INPUT_FEATURES_DIM=14, USE_BATCH_NORM=False)
+    tc = TrainConfig(BATCH_SIZE=8, BUFFER_CAPACITY=100, MIN_BUFFER_SIZE_TO_TRAIN=8, DEVICE="cpu", MAX_TRAINING_STEPS=10, USE_PER=False,
+                     LEARNING_RATE=1e-2)
+    return env, mc, tc
+
+
+def _make_batch(n, seed):
+    from alphatriangle_amd.rl.core.trainer import TensorBatch
+
+    g = torch.Generator().manual_seed(seed)
+    pol = torch.rand(n, 9, generator=g)
+    return TensorBatch(torch.rand(n, 1, 3, 3, generator=g), torch.rand(n, 14, generator=g), pol / pol.sum(1, keepdim=True),
+                       torch.empty(n).uniform_(-3, 3, generator=g), torch.ones(n))
+
+
+def _dp_train(rank, world, init, out_path):
+    from alphatriangle_amd.models import NeuralNetwork
+    from alphatriangle_amd.rl.core.trainer import TensorBatch, Trainer
+
+    torch.set_num_threads(1)
+    ctx = init_distributed(rank, world, rank, backend="gloo", init_method=init, timeout_s=60)
+    env, mc, tc = _tiny_cfg()
+    torch.manual_seed(0)
+    net = NeuralNetwork(mc, env, tc, torch.device("cpu"))
+    tr = Trainer(net, tc, env, grad_sync=ctx.grad_sync, world_size=world)
+    full = _make_batch(8, 123)
+    lo, hi = rank * 4, rank * 4 + 4
+    shard = TensorBatch(full.grid[lo:hi], full.other[lo:hi], full.policy_target[lo:hi], full.returns[lo:hi], full.weights[lo:hi])
+    for _ in range(3):
+        tr.train_step_tensors(shard)
+    if rank == 0:
+        torch.save(tr.flat.flat_param.clone(), out_path)
+    # replicas stay bit-identical without any weight broadcast
+    other = tr.flat.flat_param.clone()
+    ctx.broadcast_weights(other, src=0)
+    assert torch.equal(other, tr.flat.flat_param)
+    ctx.shutdown()
+
+
+def test_data_parallel_learner_equals_single_process(tmp_path):
+    from alphatriangle_amd.models import NeuralNetwork
+    from alphatriangle_amd.rl.core.trainer import Trainer
+
+    out = str(tmp_path / "dp.pt")
+    _spawn(_dp_train, 2, out)
+    env, mc, tc = _tiny_cfg()
+    torch.manual_seed(0)
+    net = NeuralNetwork(mc, env, tc, torch.device("cpu"))
+    tr = Trainer(net, tc, env, fused=True)
+    full = _make_batch(8, 123)
+    for _ in range(3):
+        tr.train_step_tensors(full)
+    dp = torch.load(out, weights_only=True)
+    assert torch.allclose(dp, tr.flat.flat_param, atol=1e-6), (dp - tr.flat.flat_param).abs().max()
+
+
+def _split_roles(rank, world, init):
+    torch.set_num_threads(1)
+    ctx = init_distributed(rank, world, rank, backend="gloo", layout="split", num_learners=1, init_method=init, timeout_s=60)
+    assert ctx.is_learner == (rank == 0) and ctx.is_actor == (rank != 0) and ctx.num_learners == 1
+    layout = RecordLayout(grid=9, other=14, policy=9)
+    ship = ExperienceShipper(ctx, layout, capacity=8, device=torch.device("cpu"))
+    recs = None
+    if ctx.is_actor:
+        n = rank + 1  # actor 1 ships 2 records, actor 2 ships 3
+        recs = layout.pack(torch.full((n, 1, 3, 3), float(rank)), torch.zeros(n, 14), torch.full((n, 9), 1 / 9), torch.full((n,), 0.5 * rank))
+    got = ship.exchange(recs)
+    if ctx.is_learner:
+        assert got.shape == (5, layout.stride)
+        g, o, p, r = layout.unpack(got)
+        assert sorted(r.tolist()) == [0.5, 0.5, 1.0, 1.0, 1.0] and torch.allclose(p.sum(1), torch.ones(5))
+    else:
+        assert got.shape[0] == 0
+    # learner -> actors weight push
+    w = torch.arange(5.0) if ctx.is_learner else torch.zeros(5)
+    ctx.broadcast_weights(w)
+    assert torch.equal(w, torch.arange(5.0))
+    ctx.grad_sync(torch.ones(3))  # single learner: no-op, must not hang
+    ctx.shutdown()
+
+
+def test_split_roles_experience_shipping_three_ranks():
+    _spawn(_split_roles, 3)
+
+
+def test_role_layout():
+    r = RoleLayout.build(8, "split", 1)
+    assert r.learner_ranks == [0] and r.actor_ranks == list(range(1, 8)) and not r.colocated
+    c = RoleLayout.build(4, "colocated", 1)
+    assert c.learner_ranks == c.actor_ranks == [0, 1, 2, 3] and c.colocated
+    assert RoleLayout.build(1, "split", 1).colocated

@@ -1,0 +1,67 @@
+import logging
+
+import numpy as np
+import pytest
+import torch
+
+from alphatriangle_amd.logging_config import setup_logging
+from alphatriangle_amd.utils import SumTree, format_eta, get_device, is_point_in_polygon, normalize_color_for_matplotlib, set_random_seeds
+
+
+def test_format_eta():
+    assert format_eta(None) == "N/A" and format_eta(-1) == "N/A" and format_eta(float("nan")) == "N/A"
+    assert format_eta(5) == "5s" and format_eta(65) == "1m 05s" and format_eta(3725) == "1h 02m 05s"
+    assert format_eta(3600 * 24 * 31) == ">1 month"
+
+
+def test_device_and_seeds():
+    assert get_device("cpu").type == "cpu"
+    assert get_device("auto").type in ("cpu", "cuda", "mps")
+    set_random_seeds(3)
+    a = torch.rand(2)
+    set_random_seeds(3)
+    assert torch.equal(a, torch.rand(2))
+
+
+def test_color_and_polygon():
+    assert normalize_color_for_matplotlib((255, 0, 127.5)) == (1.0, 0.0, 0.5)
+    assert normalize_color_for_matplotlib("x") == (0.0, 0.0, 0.0)  # type: ignore[arg-type]
+    sq = [(0, 0), (2, 0), (2, 2), (0, 2)]
+    assert is_point_in_polygon((1, 1), sq) and not is_point_in_polygon((3, 1), sq)
+    assert is_point_in_polygon((0, 1), sq) and is_point_in_polygon((2, 2), sq)  # boundary counts
+    assert not is_point_in_polygon((1, 1), [(0, 0), (1, 1)])
+
+
+def test_sumtree_matches_reference_semantics():
+    t = SumTree(5)
+    assert len(t.tree) == 9 and t.max_priority == 1.0 and t.total_priority == 0.0
+    for i, p in enumerate([1.0, 2.0, 3.0]):
+        t.add(p, ("exp", i))
+    assert t.n_entries == 3 and t.data_pointer == 3 and abs(t.total_priority - 6.0) < 1e-12 and t.max_priority == 3.0
+    idx, p, d = t.get_leaf(0.5)
+    assert (idx, p, d) == (4, 1.0, ("exp", 0))
+    idx, p, d = t.get_leaf(1.0)  # value <= left goes left
+    assert idx == 4
+    idx, p, d = t.get_leaf(2.5)
+    assert (idx, p, d) == (5, 2.0, ("exp", 1))
+    t.update(5, 0.5)
+    assert abs(t.total_priority - 4.5) < 1e-12 and t.tree[5] == 0.5
+    for i in range(4):  # wrap around
+        t.add(1.0, ("new", i))
+    assert t.n_entries == 5 and t.data_pointer == 2 and t.data[0] == ("new", 2)
+    li, pr = t.get_leaf_batch(np.array([0.1, t.total_priority - 1e-9]))
+    assert li[0] == 7 and li[1] >= 4  # leftmost leaf of a 9-node tree is index 7 (data slot 3)
+    with pytest.raises(ValueError):
+        SumTree(0)
+
+
+def test_setup_logging(tmp_path):
+    fh = setup_logging("debug", tmp_path / "x" / "run.log")
+    assert fh is not None
+    logging.getLogger("t").info("hello")
+    fh.flush()
+    assert "hello" in (tmp_path / "x" / "run.log").read_text()
+    root = logging.getLogger()
+    assert root.level == logging.DEBUG and any(isinstance(h, logging.StreamHandler) for h in root.handlers)
+    setup_logging("INFO")
+    assert len(logging.getLogger().handlers) == 1
