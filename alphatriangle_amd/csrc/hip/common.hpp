@@ -14,12 +14,23 @@ __device__ __forceinline__ float bf16_to_float(unsigned short h) {
   return __uint_as_float(((unsigned int)h) << 16);
 }
 
-// Round-to-nearest-even f32 -> bf16.  NaN stays NaN (quiet bit forced).
+typedef __attribute__((ext_vector_type(2))) float float2v;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+typedef __attribute__((ext_vector_type(4))) unsigned int uint4v;
+
+// Round-to-nearest-even f32 -> bf16 on the gfx950 converter (v_cvt_pk_bf16_f32).
 __device__ __forceinline__ unsigned short float_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+// Two floats -> one dword of two bf16 (lo in bits 0..15): a single v_cvt_pk_bf16_f32.
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  float2v v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2v));
+}
+// Eight floats -> one MFMA fragment / one 16-byte store.
+__device__ __forceinline__ short8 pack_bf16x8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+  uint4v u = {pack_bf16x2(a0, a1), pack_bf16x2(a2, a3), pack_bf16x2(a4, a5), pack_bf16x2(a6, a7)};
+  return __builtin_bit_cast(short8, u);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

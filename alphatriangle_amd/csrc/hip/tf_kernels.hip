@@ -1,0 +1,413 @@
+// Fused pre-LN Transformer encoder layer for gfx950, two kernels per layer, one
+// workgroup per sample (up to 128 tokens, d_model = 128, 4 heads of 32):
+//
+//   attn_block_kernel : y = x + OutProj(MHA(LayerNorm1(x)))
+//   ffn_block_kernel  : z = y + W2 act(W1 LayerNorm2(y))
+//
+// Layer definition: nn.TransformerEncoderLayer(norm_first=True) as instantiated at
+// alphatriangle/nn/model.py:189-196.
+//
+// Each kernel reads its input tile once from HBM and writes its output once; everything
+// in between lives in LDS (the normalised tile, 34 KB) or in registers:
+//   * wave w owns head w.  Q_w and K_w are produced with the weights as the MFMA A operand,
+//     which leaves each lane holding 8 consecutive head dims of one token - exactly the
+//     A/B fragment layout of the score product, so they go accumulator -> bf16 -> operand
+//     with no LDS round trip.  V_w is produced with the operands swapped, which yields the
+//     V^T fragments of the P.V product directly.
+//   * scores are computed key-major (S^T = K Q^T) so softmax reductions are in-lane plus two
+//     shuffles and P^T feeds P.V from registers.
+//   * the FFN hidden layer is processed in 128-wide halves through one 34 KB LDS tile, the
+//     second GEMM accumulating across halves in registers.
+// 70 KB of LDS and < 256 VGPRs per workgroup: two workgroups per CU overlap one's HBM
+// phase with the other's MFMA phase.
+#include "common.hpp"
+
+using namespace atrihip;
+
+namespace {
+constexpr int kD = 128;          // d_model handled by these kernels
+constexpr int kStride = 272;     // LDS bytes per token row (256 + 16 pad)
+constexpr int kRows = 128;       // token rows per tile (8 M-tiles of 16)
+constexpr int kTileBytes = kRows * kStride;
+
+__device__ __forceinline__ short8 pack8(const float4v& lo, const float4v& hi) {
+  return pack_bf16x8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+}
+
+// Stage one sample's [HW][128] bf16 tile into LDS (rows >= HW zeroed), loads issued before writes.
+__device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ src, unsigned char* lds, int HW, int tid) {
+  const int nchunks = HW * 16;
+  uint4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + i * 256;
+    v[i] = make_uint4(0, 0, 0, 0);
+    if (c < nchunks) v[i] = *reinterpret_cast<const uint4*>(src + (size_t)c * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + i * 256;  // 2048 chunks = 128 rows x 16
+    *reinterpret_cast<uint4*>(lds + (c >> 4) * kStride + (c & 15) * 16) = v[i];
+  }
+}
+
+// In-place LayerNorm of rows < HW (one thread per row).
+__device__ __forceinline__ void layernorm_rows(unsigned char* lds, int HW, const float* __restrict__ g,
+                                               const float* __restrict__ b, float eps, int tid) {
+  if (tid < HW) {
+    unsigned char* rowp = lds + tid * kStride;
+    float s = 0.f, ss = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+      short8 v = *reinterpret_cast<const short8*>(rowp + c * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = bf16_to_float((unsigned short)v[j]);
+        s += x;
+        ss += x * x;
+      }
+    }
+    const float mean = s * (1.0f / kD);
+    const float rstd = rsqrtf(fmaxf(ss * (1.0f / kD) - mean * mean, 0.f) + eps);
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+      short8 v = *reinterpret_cast<const short8*>(rowp + c * 16);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_to_float((unsigned short)v[j]) - mean) * rstd * g[c * 8 + j] + b[c * 8 + j];
+      *reinterpret_cast<short8*>(rowp + c * 16) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+
+// acc[t][n] (+)= W-fragments (A operand) x LDS tile rows (B operand), K = 128 (4 steps).
+// wp points at this wave's fragment stream for the first step; consecutive steps are 512 short8 apart.
+__device__ __forceinline__ void gemm_k128_wA(float4v (&acc)[8][2], const short8* __restrict__ wp, const unsigned char* tile,
+                                             int l15, int q4) {
+  short8 b0 = wp[0], b1 = wp[64];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    short8 nb0 = b0, nb1 = b1;
+    if (kc < 3) {
+      nb0 = wp[(kc + 1) * 512];
+      nb1 = wp[(kc + 1) * 512 + 64];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const short8 xv = *reinterpret_cast<const short8*>(tile + (t * 16 + l15) * kStride + kc * 64 + q4 * 16);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, xv, acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, xv, acc[t][1], 0, 0, 0);
+    }
+    b0 = nb0;
+    b1 = nb1;
+    __builtin_amdgcn_sched_barrier(0);  // bound the LDS reads in flight to one K step (32 registers)
+  }
+}
+}  // namespace
+
+struct AttnBlockArgs {
+  const unsigned short* x;     // [B, HW, 128] bf16
+  unsigned short* out;         // [B, HW, 128] bf16
+  const unsigned short* wqkv;  // packed [3 blocks][4 steps][4 waves][2][64][8] (Q pre-scaled by 1/sqrt(32))
+  const float* bqkv;           // [384]
+  const unsigned short* wo;    // packed [1][4][4][2][64][8]
+  const float* bo;             // [128]
+  const float* ln_g;
+  const float* ln_b;
+  int B, HW;
+  float ln_eps;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xn = smem;
+  unsigned char* ao = smem + kTileBytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.x;
+  const int HW = a.HW;
+  const unsigned short* xg = a.x + (size_t)b * HW * kD;
+
+  stage_tile(xg, xn, HW, tid);
+  // rows >= HW of the attention-output tile are padding for the out-projection: keep them finite
+  for (int c = tid + HW * 16; c < kRows * 16; c += 256) *reinterpret_cast<uint4*>(ao + (c >> 4) * kStride + (c & 15) * 16) = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  layernorm_rows(xn, HW, a.ln_g, a.ln_b, a.ln_eps, tid);
+  __syncthreads();
+
+  const short8* wq = reinterpret_cast<const short8*>(a.wqkv) + (size_t)wave * 128 + lane;
+  short8 Qf[8], Kf[8], VTf[4][2];
+  {  // ---- Q_w : lane ends with dims 8q4..8q4+7 of token (t*16 + l15)
+    float4v acc[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+    gemm_k128_wA(acc, wq, xn, l15, q4);
+    float bias[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[wave * 32 + q4 * 8 + i];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[t][0][j] += bias[j];
+        acc[t][1][j] += bias[4 + j];
+      }
+      Qf[t] = pack8(acc[t][0], acc[t][1]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {  // ---- K_w
+    float4v acc[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+    gemm_k128_wA(acc, wq + (size_t)4 * 512, xn, l15, q4);
+    float bias[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[kD + wave * 32 + q4 * 8 + i];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[t][0][j] += bias[j];
+        acc[t][1][j] += bias[4 + j];
+      }
+      Kf[t] = pack8(acc[t][0], acc[t][1]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {  // ---- V_w with swapped operands: acc[t][n][j] = V[token t*16 + 4q4 + j][dim perm(l15, n)]
+    float4v acc[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+    const short8* wv = wq + (size_t)8 * 512;
+    short8 b0 = wv[0], b1 = wv[64];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      short8 nb0 = b0, nb1 = b1;
+      if (kc < 3) {
+        nb0 = wv[(kc + 1) * 512];
+        nb1 = wv[(kc + 1) * 512 + 64];
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const short8 xv = *reinterpret_cast<const short8*>(xn + (t * 16 + l15) * kStride + kc * 64 + q4 * 16);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, b0, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, b1, acc[t][1], 0, 0, 0);
+      }
+      b0 = nb0;
+      b1 = nb1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int chp = (l15 >> 2) * 8 + (l15 & 3);
+    const float bv0 = a.bqkv[2 * kD + wave * 32 + chp], bv1 = a.bqkv[2 * kD + wave * 32 + chp + 4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[t][0][j] += bv0;
+        acc[t][1][j] += bv1;
+      }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      VTf[kb][0] = pack8(acc[2 * kb][0], acc[2 * kb + 1][0]);
+      VTf[kb][1] = pack8(acc[2 * kb][1], acc[2 * kb + 1][1]);
+    }
+  }
+
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- attention of head `wave`, one 16-query tile at a time
+  const int n_qt = (HW + 15) >> 4;
+#pragma unroll
+  for (int qt = 0; qt < 8; ++qt) {
+    if (qt >= n_qt) break;
+    __builtin_amdgcn_sched_barrier(0);  // keep q-tiles from interleaving: each holds 32 score registers
+    float4v st[8];
+    float m = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt], Qf[qt], (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
+        m = fmaxf(m, st[kt][j]);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p = __expf(st[kt][j] - m);
+        st[kt][j] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const short8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][0], pf, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][1], pf, o1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o0[j] *= inv;
+      o1[j] *= inv;
+    }
+    // lane holds channels wave*32 + q4*8 .. +7 of query qt*16 + l15
+    *reinterpret_cast<short8*>(ao + (qt * 16 + l15) * kStride + wave * 64 + q4 * 16) = pack8(o0, o1);
+  }
+  __syncthreads();
+
+  // ---- output projection + residual
+  float4v acc[8][2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+  gemm_k128_wA(acc, reinterpret_cast<const short8*>(a.wo) + (size_t)wave * 128 + lane, ao, l15, q4);
+  const int ch0 = wave * 32 + q4 * 8;
+  float bias[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bias[i] = a.bo[ch0 + i];
+  unsigned short* og = a.out + (size_t)b * HW * kD;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    int r = t * 16 + l15;
+    asm volatile("" : "+v"(r));
+    if (r >= HW) continue;
+    const short8 rv = *reinterpret_cast<const short8*>(xg + (size_t)r * kD + ch0);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = acc[t][0][j] + bias[j] + bf16_to_float((unsigned short)rv[j]);
+      o[4 + j] = acc[t][1][j] + bias[4 + j] + bf16_to_float((unsigned short)rv[4 + j]);
+    }
+    *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+  }
+}
+
+struct FfnBlockArgs {
+  const unsigned short* y;   // [B, HW, 128]
+  unsigned short* out;       // [B, HW, 128]
+  const unsigned short* w1;  // packed [F/128 blocks][4 steps]...
+  const float* b1;           // [F]
+  const unsigned short* w2;  // packed [1][F/32 steps]...
+  const float* b2;           // [128]
+  const float* ln_g;
+  const float* ln_b;
+  int B, HW, F, act;
+  float ln_eps;
+};
+
+__global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* yn = smem;
+  unsigned char* hh = smem + kTileBytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.x;
+  const int HW = a.HW;
+  const unsigned short* yg = a.y + (size_t)b * HW * kD;
+
+  stage_tile(yg, yn, HW, tid);
+  __syncthreads();
+  layernorm_rows(yn, HW, a.ln_g, a.ln_b, a.ln_eps, tid);
+  __syncthreads();
+
+  float4v acc_o[8][2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc_o[t][0] = acc_o[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+  const int ch0 = wave * 32 + q4 * 8;
+  const int halves = a.F >> 7;
+  for (int h = 0; h < halves; ++h) {
+    {
+      float4v acc_h[8][2];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc_h[t][0] = acc_h[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+      gemm_k128_wA(acc_h, reinterpret_cast<const short8*>(a.w1) + ((size_t)h * 4 * 4 + wave) * 128 + lane, yn, l15, q4);
+      float bias[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bias[i] = a.b1[h * 128 + ch0 + i];
+      if (h > 0) __syncthreads();  // the previous half's second GEMM has finished reading the hidden tile
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc_h[t][0][j] + bias[j];
+          v[4 + j] = acc_h[t][1][j] + bias[4 + j];
+        }
+        if (a.act == kActReLU) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752f));
+        }
+        *reinterpret_cast<short8*>(hh + (t * 16 + l15) * kStride + wave * 64 + q4 * 16) =
+            pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+      }
+    }
+    __syncthreads();
+    gemm_k128_wA(acc_o, reinterpret_cast<const short8*>(a.w2) + ((size_t)h * 4 * 4 + wave) * 128 + lane, hh, l15, q4);
+  }
+
+  float bias[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bias[i] = a.b2[ch0 + i];
+  unsigned short* og = a.out + (size_t)b * HW * kD;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    int r = t * 16 + l15;
+    asm volatile("" : "+v"(r));
+    if (r >= HW) continue;
+    const short8 rv = *reinterpret_cast<const short8*>(yg + (size_t)r * kD + ch0);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = acc_o[t][0][j] + bias[j] + bf16_to_float((unsigned short)rv[j]);
+      o[4 + j] = acc_o[t][1][j] + bias[4 + j] + bf16_to_float((unsigned short)rv[4 + j]);
+    }
+    *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+  }
+}
+
+extern "C" {
+
+int atri_attn_block(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                    const float* ln_g, const float* ln_b, int B, int HW, int D, int heads, float ln_eps,
+                    hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (D != kD || heads != 4 || HW > kRows || HW < 1) return -10;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
+    attr = true;
+  }
+  AttnBlockArgs a{(const unsigned short*)x, (unsigned short*)out, (const unsigned short*)wqkv, bqkv,
+                  (const unsigned short*)wo, bo, ln_g, ln_b, B, HW, ln_eps};
+  hipLaunchKernelGGL(attn_block_kernel, dim3(B), dim3(256), 2 * kTileBytes, stream, a);
+  return (int)hipGetLastError();
+}
+
+int atri_ffn_block(const void* y, void* out, const void* w1, const float* b1, const void* w2, const float* b2,
+                   const float* ln_g, const float* ln_b, int B, int HW, int D, int F, int act, float ln_eps,
+                   hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (D != kD || (F & 127) != 0 || F < 128 || HW > kRows || HW < 1) return -10;
+  if (act != kActReLU && act != kActGELU) return -11;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)ffn_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
+    attr = true;
+  }
+  FfnBlockArgs a{(const unsigned short*)y, (unsigned short*)out, (const unsigned short*)w1, b1,
+                 (const unsigned short*)w2, b2, ln_g, ln_b, B, HW, F, act, ln_eps};
+  hipLaunchKernelGGL(ffn_block_kernel, dim3(B), dim3(256), 2 * kTileBytes, stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -13,6 +13,8 @@ Layer -> kernel map (default config, B leaves, HW = 120 tokens):
   1x1 projections, QKV, out-proj, FFN    tile_gemm_kernel taps=1  (+LayerNorm prologue,
                                          residual / activation / positional epilogue)
   4-head attention                       attention_kernel         (MFMA, softmax in registers)
+  encoder layer, d_model 128 / <=128 tok attn_block_kernel + ffn_block_kernel (tf_kernels.hip; replaces the
+                                         five launches above with two, activations stay in LDS / registers)
   final LayerNorm + flatten              rows_to_fc_kernel
   shared FC (K = 15390)                  fc_splitk_kernel + fc_finish_kernel
   policy / value heads                   tile_gemm_kernel taps=1 (rows = samples)
@@ -202,6 +204,11 @@ class InferenceEngine:
         self.cap = 0
         self.loaded = False
         self.fc_sk = 8
+        # one-workgroup-per-sample fused encoder-layer kernels (csrc/hip/tf_kernels.hip)
+        self.fused_tf = bool(
+            self.uses_tf and model_config.TRANSFORMER_DIM == 128 and model_config.TRANSFORMER_HEADS == 4
+            and self.HW <= 128 and model_config.TRANSFORMER_FC_DIM % 128 == 0
+        )
         self._store: list[torch.Tensor] = []
         self._store_cursor = 0
 
@@ -409,6 +416,16 @@ class InferenceEngine:
             for tl in self.tf_layers:
                 free = [i for i in range(5) if i != x]
                 q, t, y, h = free[0], free[1], free[2], free[3]
+                if self.fused_tf:
+                    qkv, out, ff1, ff2 = tl["qkv"], tl["out"], tl["ff1"], tl["ff2"]
+                    hb.call("atri_attn_block", hb.ptr(bufs[x]), hb.ptr(bufs[y]), hb.ptr(qkv.w), hb.ptr(qkv.bias),
+                            hb.ptr(out.w), hb.ptr(out.bias), hb.ptr(qkv.ln_g), hb.ptr(qkv.ln_b), hb.i32(B), hb.i32(self.HW),
+                            hb.i32(D), hb.i32(heads), hb.f32(qkv.ln_eps))
+                    hb.call("atri_ffn_block", hb.ptr(bufs[y]), hb.ptr(bufs[q]), hb.ptr(ff1.w), hb.ptr(ff1.bias),
+                            hb.ptr(ff2.w), hb.ptr(ff2.bias), hb.ptr(ff1.ln_g), hb.ptr(ff1.ln_b), hb.i32(B), hb.i32(self.HW),
+                            hb.i32(D), hb.i32(ff1.cout), hb.i32(self.act), hb.f32(ff1.ln_eps))
+                    x = q
+                    continue
                 self._run_gemm(tl["qkv"], bufs[x], bufs[q], rows, conv=True)
                 hb.call("atri_attention", hb.ptr(bufs[q]), hb.ptr(bufs[t]), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads))
                 self._run_gemm(tl["out"], bufs[t], bufs[y], rows, conv=True, residual=bufs[x])

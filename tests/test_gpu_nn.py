@@ -155,3 +155,74 @@ def test_engine_forward_matches_pytorch_module(preset):
     # policy agreement where it matters: same top action for nearly every sample
     agree = (logits.argmax(1) == ref_logits.argmax(1)).float().mean().item()
     assert agree > 0.8
+
+
+@pytest.mark.parametrize("hw,act_name", [(120, "relu"), (63, "gelu"), (128, "relu"), (16, "relu")])
+def test_fused_encoder_layer_matches_torch(hw, act_name):
+    """attn_block + ffn_block kernels vs nn.TransformerEncoderLayer(norm_first=True) in fp32."""
+    from alphatriangle_amd.ops import hipbind as hb
+    from alphatriangle_amd.ops.inference import pack_gemm_weights
+
+    torch.manual_seed(5)
+    dev = _dev()
+    B, D, Fd, heads = 9, 128, 256, 4
+    layer = torch.nn.TransformerEncoderLayer(D, heads, Fd, dropout=0.0, activation=act_name, batch_first=True, norm_first=True).to(dev).eval()
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(_bf16_round(p + 0.05 * torch.randn_like(p)))
+    x = _bf16_round(torch.randn(B, hw, D, device=dev))
+    with torch.no_grad():
+        ref_y = x + layer._sa_block(layer.norm1(x), None, None)
+        ref_z = layer(x)
+
+    def pk(w_nk):  # [N, K] -> packed fragments, padded bias handled by caller
+        return pack_gemm_weights(w_nk.detach().float().t().unsqueeze(0).contiguous(), dev)[0]
+
+    w_in = layer.self_attn.in_proj_weight.detach().float().clone()
+    b_in = layer.self_attn.in_proj_bias.detach().float().clone()
+    w_in[:D] *= 1.0 / math.sqrt(32)
+    b_in[:D] *= 1.0 / math.sqrt(32)
+    xb = x.to(torch.bfloat16).contiguous()
+    y = torch.zeros_like(xb)
+    z = torch.zeros_like(xb)
+    # keep every packed tensor alive until the kernels have run (the caching allocator reuses freed blocks)
+    w_qkv, w_o, w_1, w_2 = pk(w_in), pk(layer.self_attn.out_proj.weight), pk(layer.linear1.weight), pk(layer.linear2.weight)
+    hb.call("atri_attn_block", hb.ptr(xb), hb.ptr(y), hb.ptr(w_qkv), hb.ptr(b_in),
+            hb.ptr(w_o), hb.ptr(layer.self_attn.out_proj.bias.detach().float().contiguous()),
+            hb.ptr(layer.norm1.weight.detach().float().contiguous()), hb.ptr(layer.norm1.bias.detach().float().contiguous()),
+            hb.i32(B), hb.i32(hw), hb.i32(D), hb.i32(heads), hb.f32(layer.norm1.eps))
+    act_id = 1 if act_name == "relu" else 2
+    hb.call("atri_ffn_block", hb.ptr(y), hb.ptr(z), hb.ptr(w_1), hb.ptr(layer.linear1.bias.detach().float().contiguous()),
+            hb.ptr(w_2), hb.ptr(layer.linear2.bias.detach().float().contiguous()),
+            hb.ptr(layer.norm2.weight.detach().float().contiguous()), hb.ptr(layer.norm2.bias.detach().float().contiguous()),
+            hb.i32(B), hb.i32(hw), hb.i32(D), hb.i32(Fd), hb.i32(act_id), hb.f32(layer.norm2.eps))
+    torch.cuda.synchronize()
+    yerr = (y.float() - ref_y).abs().max().item()
+    zerr = (z.float() - ref_z).abs().max().item()
+    assert yerr < 0.06, f"attention block err {yerr}"
+    assert zerr < 0.08, f"layer err {zerr}"
+
+
+def test_fused_and_unfused_encoder_paths_agree():
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(6)
+    dev = _dev()
+    env, mc = EnvConfig(), ModelConfig()
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev)
+    eng = net.engine
+    assert eng is not None and eng.fused_tf
+    B = 21
+    grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    l1, v1 = eng.forward(grid, other)
+    l1, v1 = l1.clone(), v1.clone()
+    eng.fused_tf = False
+    try:
+        l2, v2 = eng.forward(grid, other)
+        l2, v2 = l2.clone(), v2.clone()
+    finally:
+        eng.fused_tf = True
+    torch.cuda.synchronize()
+    assert (l1 - l2).abs().max().item() < 0.05
+    assert (v1 - v2).abs().max().item() < 0.1
