@@ -1,0 +1,288 @@
+// 3x3 / stride 1 / pad 1 convolution as an MFMA implicit GEMM for boards with W <= 15 and H <= 8
+// (the default 8x15 grid), NHWC bf16 in and out, one workgroup per sample.
+//
+// Layers served: conv stem layers 1.. and both convs of every residual block
+// (alphatriangle/nn/model.py:20-37 conv_block, :40-59 ResidualBlock), BatchNorm folded.
+//
+// Design points, each one the answer to a measured cost of the generic tile kernel
+// (bench/conv_probe.py removes one ingredient at a time):
+//   * The sample is staged into LDS with a physical zero halo at a row pitch of 16 pixels
+//     (pixel (y, x) -> LDS row 16y + x + 17).  One MFMA M-tile is one image row, a 3x3 tap is a
+//     constant LDS offset, out-of-image taps read zeros: the main loop has no per-lane address
+//     math at all (it was ~40 % of the old loop's time), only ds_read with immediate offsets.
+//   * The accumulators leave through LDS: lanes hold (pixel, 8 channels) fragments whose direct
+//     16-byte stores touch 16 different rows per instruction (1.5 TB/s measured); after the
+//     transpose each wave writes whole 256-byte rows, and the residual / positional table
+//     are read with the same coalesced pattern.
+//   * 44 KB of LDS and ~110 VGPRs per workgroup: three workgroups (12 waves) per CU overlap
+//     staging, MFMA and write-back phases of different samples.
+#include "common.hpp"
+
+using namespace atrihip;
+
+struct RowConvArgs {
+  const unsigned short* in;        // [B, HW, Cin] bf16
+  const unsigned short* w;         // packed fragments [NB][9*KC][wave 4][n 2][lane 64][8] (+1 spare step)
+  const float* bias;               // [NB*128]
+  const unsigned short* residual;  // [B, HW, Cout] bf16 or nullptr (added before the activation)
+  const float* post_add;           // [HW, Cout] f32 or nullptr (added after the activation)
+  unsigned short* out;             // [B, HW, Cout] bf16
+  int B, H, W, HW, Cin, Cout, act, n_blocks, log2_cpr, out_off, ymagic;
+};
+
+namespace {
+constexpr int kInRows = 162;     // (8 + 2) * 16 + 2 halo-padded pixel rows
+constexpr int kOutStride = 272;  // bytes per row of the 128-channel output staging tile
+
+// By value on purpose: an address-taken float[8] would live in scratch memory on every path.
+__device__ __noinline__ float4v act8_slow_rc(float4v v, int act) {
+  for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], act);
+  return v;
+}
+}  // namespace
+
+// DBG != 0 instantiations are roofline probes (bench/conv_probe.py), bit mask: 1 no LDS fragment reads,
+// 2 no weight-fragment loads, 4 no main loop, 16 no input staging loads, 32 no write-back phase.
+template <int CIN, int DBG>
+__global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.x;
+  constexpr int stride = CIN * 2 + 16;
+  constexpr int KC = CIN / 32, STEPS = 9 * KC;
+  const int H = a.H, W = a.W;
+
+  // ---- stage the sample with its zero halo; eight global loads in flight per thread ----
+  {
+    const int cmask = (1 << a.log2_cpr) - 1;
+    const int total = kInRows << a.log2_cpr;
+    const unsigned short* src = a.in + (size_t)b * a.HW * a.Cin;
+    for (int c0 = tid; c0 < total; c0 += 256 * 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i * 256;
+        v[i] = make_uint4(0, 0, 0, 0);
+        const int rr = (c >> a.log2_cpr) - 17, y = rr >> 4, x = rr & 15;
+        if (!(DBG & 16) && c < total && rr >= 0 && y < H && x < W)
+          v[i] = *reinterpret_cast<const uint4*>(src + (size_t)(y * W + x) * a.Cin + (c & cmask) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i * 256;
+        if (c < total) *reinterpret_cast<uint4*>(smem + (c >> a.log2_cpr) * stride + (c & cmask) * 16) = v[i];
+      }
+    }
+  }
+  __syncthreads();
+
+  // LDS byte offset (relative to lane_base) of the fragment of image row t at GEMM step st = tap*KC + kc.
+  // Compile-time after unrolling: every ds_read of the main loop uses an immediate offset.
+  const unsigned char* lane_base = smem + l15 * stride + q4 * 16;
+  unsigned char* otile = smem + a.out_off;
+#define ROWCONV_OFF(st, t) ((17 + (((st) / KC) / 3 - 1) * 16 + (((st) / KC) % 3 - 1) + (t) * 16) * stride + ((st) % KC) * 64)
+
+  for (int nb = 0; nb < a.n_blocks; ++nb) {
+    const int ch_wave = nb * 128 + wave * 32;
+    const bool active = ch_wave < a.Cout;  // wave-uniform
+    float4v acc[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
+      acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+    }
+    if (active && !(DBG & 4)) {
+      // Fully unrolled, software pipelined by hand in half steps (4 image rows = 8 MFMAs): while one half
+      // runs, the four LDS fragments of the next half are in flight, and the two weight fragments of the
+      // next step are requested a full step ahead.  sched_barrier(0) fences keep the compiler from sinking
+      // those loads down to their first use (which would serialise every load with the MFMA that needs it).
+      const short8* wp = reinterpret_cast<const short8*>(a.w) + ((size_t)nb * STEPS * 4 + wave) * 128 + lane;
+      short8 wb[2][2], av[2][4];
+      wb[0][0] = wp[0];
+      wb[0][1] = wp[64];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) av[0][t] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_OFF(0, t));
+#pragma unroll
+      for (int hs = 0; hs < 2 * STEPS; ++hs) {
+        const int st = hs >> 1, half = hs & 1, cur = hs & 1, nxt = cur ^ 1, wcur = st & 1, wnxt = wcur ^ 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (half == 0 && st + 1 < STEPS) {
+          wb[wnxt][0] = (DBG & 2) ? wb[wcur][0] : wp[(size_t)(st + 1) * 512];
+          wb[wnxt][1] = (DBG & 2) ? wb[wcur][1] : wp[(size_t)(st + 1) * 512 + 64];
+        }
+        if (hs + 1 < 2 * STEPS) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            av[nxt][t] = (DBG & 1) ? av[cur][t]
+                                   : *reinterpret_cast<const short8*>(lane_base + ROWCONV_OFF((hs + 1) >> 1, ((hs + 1) & 1) * 4 + t));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          // image rows >= H are all-zero halo rows: computing them keeps the loop branch-free
+          acc[half * 4 + t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[wcur][0], av[cur][t], acc[half * 4 + t][0], 0, 0, 0);
+          acc[half * 4 + t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[wcur][1], av[cur][t], acc[half * 4 + t][1], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // every wave is done reading the input tile (the output tile may alias it)
+    if (active) {
+      float bias[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bias[i] = a.bias[ch_wave + q4 * 8 + i];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        *reinterpret_cast<short8*>(otile + (t * 16 + l15) * kOutStride + wave * 64 + q4 * 16) =
+            pack_bf16x8(acc[t][0][0] + bias[0], acc[t][0][1] + bias[1], acc[t][0][2] + bias[2], acc[t][0][3] + bias[3],
+                        acc[t][1][0] + bias[4], acc[t][1][1] + bias[5], acc[t][1][2] + bias[6], acc[t][1][3] + bias[7]);
+      }
+    }
+    __syncthreads();
+
+    // ---- coalesced write-back: thread -> (pixel, 8-channel chunk), whole rows per wave ----
+    const int n_ch = min(128, a.Cout - nb * 128);
+    int l2c = 0;
+    while ((8 << l2c) < n_ch) ++l2c;  // chunks per pixel = n_ch / 8 (power of two)
+    const int chunks = a.HW << l2c;
+    const size_t gbase = (size_t)b * a.HW * a.Cout + nb * 128;
+    for (int c0 = tid; c0 < (((DBG & 32) && acc[0][0][0] != 12345.f) ? 0 : chunks); c0 += 256 * 8) {
+      short8 rv[8];
+      if (a.residual != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = c0 + i * 256;
+          if (c < chunks)
+            rv[i] = *reinterpret_cast<const short8*>(a.residual + gbase + (size_t)(c >> l2c) * a.Cout + (c & ((1 << l2c) - 1)) * 8);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i * 256;
+        if (c >= chunks) continue;
+        const int p = c >> l2c, cc = c & ((1 << l2c) - 1);
+        const int y = (p * a.ymagic) >> 16, x = p - y * W;
+        const short8 hv = *reinterpret_cast<const short8*>(otile + (y * 16 + x) * kOutStride + cc * 16);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bf16_to_float((unsigned short)hv[j]);
+        if (a.residual != nullptr) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += bf16_to_float((unsigned short)rv[i][j]);
+        }
+        if (a.act == kActReLU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (a.act != kActNone) {
+          const float4v lo = act8_slow_rc((float4v){v[0], v[1], v[2], v[3]}, a.act);
+          const float4v hi = act8_slow_rc((float4v){v[4], v[5], v[6], v[7]}, a.act);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = lo[j];
+            v[4 + j] = hi[j];
+          }
+        }
+        if (a.post_add != nullptr) {
+          const float4* pa = reinterpret_cast<const float4*>(a.post_add + (size_t)p * a.Cout + nb * 128 + cc * 8);
+          const float4 p0 = pa[0], p1 = pa[1];
+          v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
+          v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+        }
+        *reinterpret_cast<short8*>(a.out + gbase + (size_t)p * a.Cout + cc * 8) =
+            pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+      }
+    }
+  }
+}
+
+extern "C" {
+
+// Whether atri_rowconv accepts this geometry (callers fall back to atri_tile_gemm otherwise).
+int atri_rowconv_supported(int H, int W, int Cin, int Cout) {
+  if (H < 1 || H > 8 || W < 1 || W > 15) return 0;
+  if (Cin < 32 || Cin > 128 || (Cin & (Cin - 1)) != 0) return 0;
+  if (Cout < 32 || (Cout & (Cout - 1)) != 0) return 0;
+  return 1;
+}
+
+}  // extern "C"
+
+namespace {
+template <int DBG>
+int launch_rowconv(const RowConvArgs& a, int lds, hipStream_t stream) {
+  static bool attr[3] = {false, false, false};
+  const int ci = a.Cin == 32 ? 0 : a.Cin == 64 ? 1 : 2;
+  const void* fn = ci == 0   ? (const void*)rowconv_kernel<32, DBG>
+                   : ci == 1 ? (const void*)rowconv_kernel<64, DBG>
+                             : (const void*)rowconv_kernel<128, DBG>;
+  if (!attr[ci]) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr[ci] = true;
+  }
+  if (ci == 0) hipLaunchKernelGGL((rowconv_kernel<32, DBG>), dim3(a.B), dim3(256), lds, stream, a);
+  else if (ci == 1) hipLaunchKernelGGL((rowconv_kernel<64, DBG>), dim3(a.B), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL((rowconv_kernel<128, DBG>), dim3(a.B), dim3(256), lds, stream, a);
+  return hip_err(hipGetLastError());
+}
+}  // namespace
+
+static int rowconv_impl(const void* in, const void* w, const float* bias, const void* residual, const float* post_add,
+                        void* out, int B, int H, int W, int Cin, int Cout, int act, int n_blocks, int dbg,
+                        hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (!atri_rowconv_supported(H, W, Cin, Cout)) return -10;
+  if (n_blocks * 128 < Cout) return -11;
+  RowConvArgs a;
+  a.in = (const unsigned short*)in;
+  a.w = (const unsigned short*)w;
+  a.bias = bias;
+  a.residual = (const unsigned short*)residual;
+  a.post_add = post_add;
+  a.out = (unsigned short*)out;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.HW = H * W;
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.act = act;
+  a.n_blocks = n_blocks;
+  int l2 = 0;
+  while ((1 << l2) < (Cin >> 3)) ++l2;
+  a.log2_cpr = l2;
+  const int stride = Cin * 2 + 16;
+  const int in_bytes = kInRows * stride;
+  const int out_bytes = 128 * kOutStride;
+  // one output block may reuse the input tile's LDS; several blocks need the input to survive
+  a.out_off = (n_blocks > 1) ? in_bytes : 0;
+  const int lds = (n_blocks > 1) ? in_bytes + out_bytes : (in_bytes > out_bytes ? in_bytes : out_bytes);
+  a.ymagic = 65536 / W + 1;
+  for (int p = 0; p < a.HW; ++p)
+    if (((p * a.ymagic) >> 16) != p / W) return -12;
+  switch (dbg) {
+    case 0: return launch_rowconv<0>(a, lds, stream);
+    case 1: return launch_rowconv<1>(a, lds, stream);
+    case 2: return launch_rowconv<2>(a, lds, stream);
+    case 4: return launch_rowconv<4>(a, lds, stream);
+    case 20: return launch_rowconv<20>(a, lds, stream);
+    case 36: return launch_rowconv<36>(a, lds, stream);
+    case 52: return launch_rowconv<52>(a, lds, stream);
+    default: return -14;
+  }
+}
+
+extern "C" {
+
+int atri_rowconv(const void* in, const void* w, const float* bias, const void* residual, const float* post_add, void* out,
+                 int B, int H, int W, int Cin, int Cout, int act, int n_blocks, hipStream_t stream) {
+  return rowconv_impl(in, w, bias, residual, post_add, out, B, H, W, Cin, Cout, act, n_blocks, 0, stream);
+}
+
+// Roofline probe: the same launch with ingredients removed (see the kernel's DBG parameter).
+int atri_rowconv_probe(const void* in, const void* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                       int n_blocks, int dbg, hipStream_t stream) {
+  return rowconv_impl(in, w, bias, nullptr, nullptr, out, B, H, W, Cin, Cout, kActReLU, n_blocks, dbg, stream);
+}
+
+}  // extern "C"

@@ -36,11 +36,17 @@ struct TileGemmArgs {
 };
 
 // Non-ReLU activations of eight values; kept out of line so the unrolled epilogue stays small.
-__device__ __noinline__ void act8_slow(float* v, int act) {
-  for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i], act);
+// By value on purpose: an address-taken float[8] would live in scratch memory on every path.
+__device__ __noinline__ float4v act8_slow(float4v v, int act) {
+  for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], act);
+  return v;
 }
 
-template <int MT>
+// DBG != 0 instantiations are roofline probes (bench/conv_probe.py): they drop one ingredient of the main
+// loop so its cost can be read off the timing difference; their results are numerically meaningless.
+// DBG is a bit mask: 1 no LDS fragment reads, 2 no weight-fragment loads, 4 no main loop, 8 no tap address math,
+// 16 no input staging, 32 no output stores.
+template <int MT, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(TileGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,12 +58,24 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(TileGemmArgs a) {
 
   // ---- stage the input tile (coalesced 16-byte chunks) ----
   {
-    const int cpr = 1 << a.log2_cpr;  // 16-byte chunks per row
+    // rows of the tile are contiguous in memory: chunk c is 16 bytes at in + row0*Cin + 8c.
+    // Eight loads are kept in flight per thread before the first LDS write (HBM latency paid once per batch).
+    const int cmask = (1 << a.log2_cpr) - 1;  // 16-byte chunks per row - 1
     const int nchunks = rows << a.log2_cpr;
-    for (int c = tid; c < nchunks; c += 256) {
-      int r = c >> a.log2_cpr, cc = c & (cpr - 1);
-      uint4 v = *reinterpret_cast<const uint4*>(a.in + (size_t)(row0 + r) * a.Cin + cc * 8);
-      *reinterpret_cast<uint4*>(smem + r * stride + cc * 16) = v;
+    const uint4* src = reinterpret_cast<const uint4*>(a.in + (size_t)row0 * a.Cin);
+    for (int c0 = tid; c0 < ((DBG & 16) ? 0 : nchunks); c0 += 256 * 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i * 256;
+        v[i] = make_uint4(0, 0, 0, 0);  // unconditional definition keeps the batch in registers
+        if (c < nchunks) v[i] = src[c];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i * 256;
+        if (c < nchunks) *reinterpret_cast<uint4*>(smem + (c >> a.log2_cpr) * stride + (c & cmask) * 16) = v[i];
+      }
     }
     for (int c = tid; c < (stride >> 4); c += 256) *reinterpret_cast<uint4*>(smem + zoff + c * 16) = make_uint4(0, 0, 0, 0);
   }
@@ -131,19 +149,19 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(TileGemmArgs a) {
     const short8* wp = reinterpret_cast<const short8*>(a.w) + ((size_t)nb * steps * 4 + wave) * 128 + lane;
     short8 b0 = wp[0], b1 = wp[64];
     int s = 0;
-    for (int tap = 0; tap < a.taps; ++tap) {
+    for (int tap = 0; tap < ((DBG & 4) ? 0 : a.taps); ++tap) {
       const int toff = (a.taps == 9) ? ((tap / 3 - 1) * a.W + (tap % 3 - 1)) * stride : 0;
       const int tapbit = 18 + tap;
       const int zlane = zoff + q4 * 16;
       for (int kc = 0; kc < KC; ++kc, ++s) {
         // prefetch the next step's weight fragments (the packed buffer carries one spare step)
-        const short8 nb0 = wp[(size_t)(s + 1) * 512];
-        const short8 nb1 = wp[(size_t)(s + 1) * 512 + 64];
+        const short8 nb0 = (DBG & 2) ? b0 : wp[(size_t)(s + 1) * 512];
+        const short8 nb1 = (DBG & 2) ? b1 : wp[(size_t)(s + 1) * 512 + 64];
         const int koff = kc * 64;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-          const int ad = ((packed[t] >> tapbit) & 1) ? (packed[t] & 0x3FFFF) + toff : zlane;
-          const short8 av = *reinterpret_cast<const short8*>(smem + ad + koff);
+          const int ad = (DBG & 8) ? (packed[t] & 0x3FFFF) : ((packed[t] >> tapbit) & 1) ? (packed[t] & 0x3FFFF) + toff : zlane;
+          const short8 av = (DBG & 1) ? b1 : *reinterpret_cast<const short8*>(smem + ad + koff);
           acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, av, acc[t][0], 0, 0, 0);
           acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, av, acc[t][1], 0, 0, 0);
           if ((t % 5) == 4) __builtin_amdgcn_sched_barrier(0);  // bound the LDS reads in flight (VGPR budget)
@@ -159,43 +177,62 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(TileGemmArgs a) {
       float bias[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) bias[i] = a.bias[ch0 + i];
+      constexpr int EG = (MT % 5 == 0) ? 5 : 4;  // tiles per epilogue group: residual loads of a group fly together
 #pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        int r = t * 16 + l15;
-        asm volatile("" : "+v"(r));  // keep the per-row address math out of the MFMA loop's live range
-        if (r >= rows) continue;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = acc[t][0][j] + bias[j];
-          v[4 + j] = acc[t][1][j] + bias[4 + j];
-        }
-        const size_t grow = (size_t)(row0 + r);
+      for (int t0 = 0; t0 < MT; t0 += EG) {
+        short8 rv[EG];
         if (a.residual != nullptr) {
-          short8 rv = *reinterpret_cast<const short8*>(a.residual + grow * a.Cout + ch0);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] += bf16_to_float((unsigned short)rv[i]);
+          for (int u = 0; u < EG; ++u) {
+            int r = (t0 + u) * 16 + l15;
+            asm volatile("" : "+v"(r));  // keep the per-row address math out of the MFMA loop's live range
+            rv[u] = (short8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (r < rows) rv[u] = *reinterpret_cast<const short8*>(a.residual + (size_t)(row0 + r) * a.Cout + ch0);
+          }
         }
-        if (a.act == kActReLU) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-        } else if (a.act != kActNone) {
-          act8_slow(v, a.act);
-        }
-        if (a.post_add != nullptr) {
-          const float* pa = a.post_add + (size_t)(r % a.HW) * a.Cout + ch0;
+        for (int u = 0; u < EG; ++u) {
+          const int t = t0 + u;
+          int r = t * 16 + l15;
+          asm volatile("" : "+v"(r));
+          if (r >= rows) continue;
+          if ((DBG & 32) && acc[t][0][0] != 12345.f) continue;
+          float v[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] += pa[i];
-        }
-        if (a.out_f32) {
-          float* op = reinterpret_cast<float*>(a.out) + grow * a.out_stride + ch0;
-          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          short8 o;
+          for (int j = 0; j < 4; ++j) {
+            v[j] = acc[t][0][j] + bias[j];
+            v[4 + j] = acc[t][1][j] + bias[4 + j];
+          }
+          const size_t grow = (size_t)(row0 + r);
+          if (a.residual != nullptr) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = (short)float_to_bf16(v[i]);
-          *reinterpret_cast<short8*>(reinterpret_cast<unsigned short*>(a.out) + grow * a.out_stride + ch0) = o;
+            for (int i = 0; i < 8; ++i) v[i] += bf16_to_float((unsigned short)rv[u][i]);
+          }
+          if (a.act == kActReLU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+          } else if (a.act != kActNone) {
+            const float4v lo = act8_slow((float4v){v[0], v[1], v[2], v[3]}, a.act);
+            const float4v hi = act8_slow((float4v){v[4], v[5], v[6], v[7]}, a.act);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = lo[j];
+              v[4 + j] = hi[j];
+            }
+          }
+          if (a.post_add != nullptr) {
+            const float* pa = a.post_add + (size_t)(r % a.HW) * a.Cout + ch0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += pa[i];
+          }
+          if (a.out_f32) {
+            float* op = reinterpret_cast<float*>(a.out) + grow * a.out_stride + ch0;
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            *reinterpret_cast<short8*>(reinterpret_cast<unsigned short*>(a.out) + grow * a.out_stride + ch0) =
+                pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+          }
         }
       }
     }
@@ -491,7 +528,40 @@ __global__ void c51_expect_kernel(const float* __restrict__ logits, int stride, 
 
 // ---------------------------------------------------------------------------
 // C ABI
+namespace {
+template <int MT, int DBG>
+int launch_tile_gemm_inst(const TileGemmArgs& a, int grid, size_t lds, hipStream_t stream) {
+  // the dynamic-LDS ceiling is raised once per kernel (not a stream operation: keep it out of graph capture)
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)tile_gemm_kernel<MT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((tile_gemm_kernel<MT, DBG>), dim3(grid), dim3(256), lds, stream, a);
+  return hip_err(hipGetLastError());
+}
+
+int launch_tile_gemm(const TileGemmArgs& a, hipStream_t stream, int dbg) {
+  const int grid = (a.rows_total + a.rows_per_wg - 1) / a.rows_per_wg;
+  const int stride = a.Cin * 2 + 16;
+  if (a.rows_per_wg > 240) return launch_tile_gemm_inst<16, 0>(a, grid, (size_t)(16 * 16 + 1) * stride, stream);
+  const size_t lds = (size_t)(15 * 16 + 1) * stride;
+  switch (dbg) {
+    case 0: return launch_tile_gemm_inst<15, 0>(a, grid, lds, stream);
+    case 1: return launch_tile_gemm_inst<15, 1>(a, grid, lds, stream);
+    case 2: return launch_tile_gemm_inst<15, 2>(a, grid, lds, stream);
+    case 4: return launch_tile_gemm_inst<15, 4>(a, grid, lds, stream);
+    case 8: return launch_tile_gemm_inst<15, 8>(a, grid, lds, stream);
+    case 20: return launch_tile_gemm_inst<15, 20>(a, grid, lds, stream);
+    case 36: return launch_tile_gemm_inst<15, 36>(a, grid, lds, stream);
+    case 52: return launch_tile_gemm_inst<15, 52>(a, grid, lds, stream);
+    default: return -14;
+  }
+}
+}  // namespace
+
 extern "C" {
+
 
 int atri_tile_gemm(const void* in, const void* w, const float* bias, const void* residual, const float* post_add,
                    const float* ln_g, const float* ln_b, void* out, int rows_total, int rows_per_wg, int HW, int H,
@@ -527,26 +597,38 @@ int atri_tile_gemm(const void* in, const void* w, const float* bias, const void*
   while ((1 << l2) < (Cin >> 3)) ++l2;
   a.log2_cpr = l2;
   a.ln_eps = ln_eps;
-  const int grid = (rows_total + rows_per_wg - 1) / rows_per_wg;
-  const int stride = Cin * 2 + 16;
-  // the dynamic-LDS ceiling is raised once per kernel (not a stream operation: keep it out of graph capture)
-  static bool attr15 = false, attr16 = false;
-  if (rows_per_wg <= 240) {
-    size_t lds = (size_t)(15 * 16 + 1) * stride;
-    if (!attr15) {
-      hipFuncSetAttribute((const void*)tile_gemm_kernel<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr15 = true;
-    }
-    hipLaunchKernelGGL(tile_gemm_kernel<15>, dim3(grid), dim3(256), lds, stream, a);
-  } else {
-    size_t lds = (size_t)(16 * 16 + 1) * stride;
-    if (!attr16) {
-      hipFuncSetAttribute((const void*)tile_gemm_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr16 = true;
-    }
-    hipLaunchKernelGGL(tile_gemm_kernel<16>, dim3(grid), dim3(256), lds, stream, a);
-  }
-  return hip_err(hipGetLastError());
+  return launch_tile_gemm(a, stream, 0);
+}
+
+// Roofline probe: same launch with one main-loop ingredient removed (see the kernel's DBG parameter).
+int atri_tile_gemm_probe(const void* in, const void* w, const float* bias, void* out, int rows_total, int rows_per_wg,
+                         int HW, int H, int W, int Cin, int Cout, int taps, int n_blocks, int dbg, hipStream_t stream) {
+  if (rows_total <= 0) return 0;
+  if (Cin < 32 || Cin > 512 || (Cin & (Cin - 1)) != 0) return -10;
+  if (rows_per_wg <= 0 || rows_per_wg > 240) return -11;
+  if (taps != 1 && taps != 9) return -12;
+  if ((Cout & 7) != 0 || n_blocks * 128 < Cout || dbg < 0) return -13;
+  TileGemmArgs a{};
+  a.in = (const unsigned short*)in;
+  a.w = (const unsigned short*)w;
+  a.bias = bias;
+  a.out = out;
+  a.rows_total = rows_total;
+  a.rows_per_wg = rows_per_wg;
+  a.HW = HW;
+  a.H = H;
+  a.W = W;
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.taps = taps;
+  a.act = kActReLU;
+  a.out_stride = Cout;
+  a.n_blocks = n_blocks;
+  int l2 = 0;
+  while ((1 << l2) < (Cin >> 3)) ++l2;
+  a.log2_cpr = l2;
+  a.ln_eps = 1e-5f;
+  return launch_tile_gemm(a, stream, dbg);
 }
 
 int atri_conv_first(const float* grid, const float* w, const float* bias, void* out, int rows_total, int HW, int H,

@@ -9,7 +9,8 @@ is the reference's (alphatriangle/nn/model.py:109-297).
 
 Layer -> kernel map (default config, B leaves, HW = 120 tokens):
   conv stem layer 0 (Cin = 1)            conv_first_kernel        (VALU, memory bound)
-  conv stem 1.., residual convs          tile_gemm_kernel taps=9  (MFMA implicit GEMM)
+  conv stem 1.., residual convs          rowconv_kernel (boards up to 8x15: halo tile in LDS, one sample per
+                                         workgroup, coalesced write-back) else tile_gemm_kernel taps=9
   1x1 projections, QKV, out-proj, FFN    tile_gemm_kernel taps=1  (+LayerNorm prologue,
                                          residual / activation / positional epilogue)
   4-head attention                       attention_kernel         (MFMA, softmax in registers)
@@ -209,6 +210,7 @@ class InferenceEngine:
             self.uses_tf and model_config.TRANSFORMER_DIM == 128 and model_config.TRANSFORMER_HEADS == 4
             and self.HW <= 128 and model_config.TRANSFORMER_FC_DIM % 128 == 0
         )
+        self.use_rowconv = True  # tests flip this to cover the generic tile kernel on small boards
         self._store: list[torch.Tensor] = []
         self._store_cursor = 0
 
@@ -358,6 +360,13 @@ class InferenceEngine:
     # ------------------------------------------------------------------ launches
     def _run_gemm(self, layer: _GemmLayer, src: torch.Tensor, dst: torch.Tensor, rows: int, *, conv: bool,
                   residual: torch.Tensor | None = None, out_f32: bool = False, out_stride: int | None = None) -> None:
+        if (conv and layer.taps == 9 and self.use_rowconv and not out_f32 and out_stride is None and layer.ln_g is None
+                and self.H <= 8 and self.W <= 15 and 32 <= layer.cin <= 128 and _pow2(layer.cout)):
+            # halo-tiled one-sample-per-workgroup conv (csrc/hip/conv_kernels.hip)
+            hb.call("atri_rowconv", hb.ptr(src), hb.ptr(layer.w), hb.ptr(layer.bias), hb.ptr(residual), hb.ptr(layer.post_add),
+                    hb.ptr(dst), hb.i32(rows // self.HW), hb.i32(self.H), hb.i32(self.W), hb.i32(layer.cin), hb.i32(layer.cout),
+                    hb.i32(layer.act), hb.i32(layer.n_blocks))
+            return
         if conv:
             hw, h, w, rpw = self.HW, self.H, self.W, self.rows_per_wg
         else:

@@ -226,3 +226,61 @@ def test_fused_and_unfused_encoder_paths_agree():
     torch.cuda.synchronize()
     assert (l1 - l2).abs().max().item() < 0.05
     assert (v1 - v2).abs().max().item() < 0.1
+
+
+@pytest.mark.parametrize("cin,cout,residual,act,h,w", [(32, 64, False, 1, 8, 15), (128, 128, True, 1, 8, 15), (64, 128, False, 2, 8, 15),
+                                                       (128, 256, True, 1, 8, 15), (64, 64, True, 1, 5, 9)])
+def test_rowconv_matches_torch(cin, cout, residual, act, h, w):
+    from alphatriangle_amd.ops import hipbind as hb
+    from alphatriangle_amd.ops.inference import pack_gemm_weights
+
+    torch.manual_seed(7)
+    dev = _dev()
+    B, H, W = 6, h, w
+    HW = H * W
+    x = _bf16_round(torch.randn(B, HW, cin, device=dev))
+    wt = _bf16_round(torch.randn(cout, cin, 3, 3, device=dev) * (1.0 / math.sqrt(cin * 9)))
+    bias = torch.randn(cout, device=dev)
+    res = _bf16_round(torch.randn(B, HW, cout, device=dev)) if residual else None
+    post = torch.randn(HW, cout, device=dev)
+    ref = F.conv2d(x.view(B, H, W, cin).permute(0, 3, 1, 2), wt, bias, padding=1).permute(0, 2, 3, 1).reshape(B, HW, cout)
+    if res is not None:
+        ref = ref + res
+    ref = F.relu(ref) if act == 1 else F.gelu(ref)
+    ref = ref + post[None]
+    packed, nb = pack_gemm_weights(wt.permute(2, 3, 1, 0).reshape(9, cin, cout), dev)
+    bpad = torch.zeros(nb * 128, device=dev)
+    bpad[:cout] = bias
+    out = torch.zeros(B * HW, cout, dtype=torch.bfloat16, device=dev)
+    xb = x.to(torch.bfloat16).contiguous()
+    rb = res.to(torch.bfloat16).contiguous() if res is not None else None
+    hb.call("atri_rowconv", hb.ptr(xb), hb.ptr(packed), hb.ptr(bpad), hb.ptr(rb), hb.ptr(post), hb.ptr(out),
+            hb.i32(B), hb.i32(H), hb.i32(W), hb.i32(cin), hb.i32(cout), hb.i32(act), hb.i32(nb))
+    torch.cuda.synchronize()
+    got = out.float().view(B, HW, cout)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 0.02 * scale + 0.03, f"max err {err} (scale {scale})"
+
+
+def test_rowconv_and_tile_gemm_paths_agree():
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(8)
+    dev = _dev()
+    env, mc = EnvConfig(), ModelConfig()
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev)
+    eng = net.engine
+    assert eng is not None and eng.use_rowconv
+    B = 19
+    grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    l1, v1 = (t.clone() for t in eng.forward(grid, other))
+    eng.use_rowconv = False
+    try:
+        l2, v2 = (t.clone() for t in eng.forward(grid, other))
+    finally:
+        eng.use_rowconv = True
+    torch.cuda.synchronize()
+    assert (l1 - l2).abs().max().item() < 0.05
+    assert (v1 - v2).abs().max().item() < 0.1
