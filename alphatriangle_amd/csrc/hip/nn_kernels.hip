@@ -275,7 +275,7 @@ __global__ void conv_first_kernel(const float* __restrict__ grid, const float* _
 // row, so the softmax row reduction is in-lane plus two shuffles and the
 // probability tile feeds the P.V product as the B operand straight from registers
 // (only V goes through LDS, to gather its column-major fragments).
-// qkv: [B, HW, 3*D] bf16 (Q pre-scaled by 1/sqrt(32)), out: [B, HW, D] bf16.
+// qkv: [B, HW, 3*D] bf16 (Q pre-scaled by log2(e)/sqrt(32): the softmax uses exp2), out: [B, HW, D] bf16.
 template <int NKT>
 __global__ __launch_bounds__(256) void attention_kernel(const unsigned short* __restrict__ qkv,
                                                         unsigned short* __restrict__ out, int B, int HW, int D,
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const unsigned short* __
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float p = __expf(st[kt][j] - m);
+          float p = __builtin_amdgcn_exp2f(st[kt][j] - m);  // Q is pre-scaled by log2(e)/sqrt(32)
           st[kt][j] = p;
           sum += p;
         }

@@ -51,64 +51,119 @@ __device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ sr
   }
 }
 
-// In-place LayerNorm of rows < HW (one thread per row).
+// In-place LayerNorm of rows < HW: two adjacent lanes per row (eight 16-byte chunks each), statistics
+// combined with one cross-lane exchange.  Every lane of a wave reaches the shuffles.
 __device__ __forceinline__ void layernorm_rows(unsigned char* lds, int HW, const float* __restrict__ g,
                                                const float* __restrict__ b, float eps, int tid) {
-  if (tid < HW) {
-    unsigned char* rowp = lds + tid * kStride;
-    float s = 0.f, ss = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < 16; ++c) {
-      short8 v = *reinterpret_cast<const short8*>(rowp + c * 16);
+  const int row = tid >> 1, c0 = (tid & 1) * 8;
+  const bool live = row < HW;
+  unsigned char* rowp = lds + (live ? row : 0) * kStride + c0 * 16;
+  short8 v[8];
+  float s = 0.f, ss = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float x = bf16_to_float((unsigned short)v[j]);
-        s += x;
-        ss += x * x;
-      }
+  for (int c = 0; c < 8; ++c) {
+    v[c] = *reinterpret_cast<const short8*>(rowp + c * 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = bf16_to_float((unsigned short)v[c][j]);
+      s += x;
+      ss += x * x;
     }
-    const float mean = s * (1.0f / kD);
-    const float rstd = rsqrtf(fmaxf(ss * (1.0f / kD) - mean * mean, 0.f) + eps);
-#pragma unroll 4
-    for (int c = 0; c < 16; ++c) {
-      short8 v = *reinterpret_cast<const short8*>(rowp + c * 16);
+  }
+  s += __shfl_xor(s, 1, 64);
+  ss += __shfl_xor(ss, 1, 64);
+  const float mean = s * (1.0f / kD);
+  const float rstd = rsqrtf(fmaxf(ss * (1.0f / kD) - mean * mean, 0.f) + eps);
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4* gp = reinterpret_cast<const float4*>(g + (c0 + c) * 8);
+      const float4* bp = reinterpret_cast<const float4*>(b + (c0 + c) * 8);
+      const float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (bf16_to_float((unsigned short)v[j]) - mean) * rstd * g[c * 8 + j] + b[c * 8 + j];
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_to_float((unsigned short)v[c][j]) - mean) * rstd * gg[j] + bb[j];
       *reinterpret_cast<short8*>(rowp + c * 16) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
     }
   }
 }
 
-// acc[t][n] (+)= W-fragments (A operand) x LDS tile rows (B operand), K = 128 (4 steps).
-// wp points at this wave's fragment stream for the first step; consecutive steps are 512 short8 apart.
-__device__ __forceinline__ void gemm_k128_wA(float4v (&acc)[8][2], const short8* __restrict__ wp, const unsigned char* tile,
-                                             int l15, int q4) {
-  short8 b0 = wp[0], b1 = wp[64];
+// The eight weight fragments (K = 128: 4 steps x 2 n-tiles) of one GEMM of this wave.  wp points at the wave's
+// fragment stream for the first step; consecutive steps are 512 short8 apart.  Requested a whole phase
+// ahead of the GEMM that uses them, so the L2 round trip is never on the critical path.
+struct WFrags {
+  short8 f[4][2];
+};
+__device__ __forceinline__ void load_wfrags(WFrags& w, const short8* __restrict__ wp) {
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int kc = 0; kc < 4; ++kc) {
-    short8 nb0 = b0, nb1 = b1;
-    if (kc < 3) {
-      nb0 = wp[(kc + 1) * 512];
-      nb1 = wp[(kc + 1) * 512 + 64];
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const short8 xv = *reinterpret_cast<const short8*>(tile + (t * 16 + l15) * kStride + kc * 64 + q4 * 16);
-      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, xv, acc[t][0], 0, 0, 0);
-      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, xv, acc[t][1], 0, 0, 0);
-    }
-    b0 = nb0;
-    b1 = nb1;
-    __builtin_amdgcn_sched_barrier(0);  // bound the LDS reads in flight to one K step (32 registers)
+    w.f[kc][0] = wp[kc * 512];
+    w.f[kc][1] = wp[kc * 512 + 64];
   }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// The residual fragment a lane needs in the epilogue (8 channels of token t*16 + l15, t = 0..7), requested
+// before the last GEMM so its HBM/L2 latency hides behind the MFMAs.
+struct ResFrags {
+  short8 r[8];
+};
+__device__ __forceinline__ void load_residual(ResFrags& rf, const unsigned short* __restrict__ rowbase, int HW, int l15) {
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int r = t * 16 + l15;
+    rf.r[t] = (short8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < HW) rf.r[t] = *reinterpret_cast<const short8*>(rowbase + (size_t)r * kD);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc[t][n] (+)= weight fragments x the LDS tile rows, K = 128 (4 steps of 32).
+// SWAP = false: weights are the MFMA A operand (lane ends with 8 consecutive output channels of token l15);
+// SWAP = true : the tile is the A operand (lane ends with 4 consecutive tokens of one output channel).
+// The LDS fragments are software pipelined in half steps (4 row tiles) between sched_barrier fences, which
+// keep the compiler from sinking each load down to the MFMA that consumes it.
+template <bool SWAP>
+__device__ __forceinline__ void gemm_k128(float4v (&acc)[8][2], const WFrags& w, const unsigned char* tile, int l15, int q4) {
+  short8 av[2][4];
+  const unsigned char* lane_base = tile + l15 * kStride + q4 * 16;
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) av[0][t] = *reinterpret_cast<const short8*>(lane_base + t * 16 * kStride);
+#pragma unroll
+  for (int hs = 0; hs < 8; ++hs) {
+    const int kc = hs >> 1, half = hs & 1, cur = hs & 1, nxt = cur ^ 1;
+    __builtin_amdgcn_sched_barrier(0);
+    if (hs + 1 < 8) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        av[nxt][t] = *reinterpret_cast<const short8*>(lane_base + (((hs + 1) & 1) * 4 + t) * 16 * kStride + ((hs + 1) >> 1) * 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int tt = half * 4 + t;
+      if (SWAP) {
+        acc[tt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[cur][t], w.f[kc][0], acc[tt][0], 0, 0, 0);
+        acc[tt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[cur][t], w.f[kc][1], acc[tt][1], 0, 0, 0);
+      } else {
+        acc[tt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f[kc][0], av[cur][t], acc[tt][0], 0, 0, 0);
+        acc[tt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f[kc][1], av[cur][t], acc[tt][1], 0, 0, 0);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
 }
 }  // namespace
 
 struct AttnBlockArgs {
   const unsigned short* x;     // [B, HW, 128] bf16
   unsigned short* out;         // [B, HW, 128] bf16
-  const unsigned short* wqkv;  // packed [3 blocks][4 steps][4 waves][2][64][8] (Q pre-scaled by 1/sqrt(32))
+  const unsigned short* wqkv;  // packed [3 blocks][4 steps][4 waves][2][64][8] (Q pre-scaled by log2(e)/sqrt(32): softmax uses exp2)
   const float* bqkv;           // [384]
   const unsigned short* wo;    // packed [1][4][4][2][64][8]
   const float* bo;             // [128]
@@ -128,6 +183,9 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   const int HW = a.HW;
   const unsigned short* xg = a.x + (size_t)b * HW * kD;
 
+  const short8* wq = reinterpret_cast<const short8*>(a.wqkv) + (size_t)wave * 128 + lane;
+  WFrags wa, wb;
+  load_wfrags(wa, wq + (size_t)4 * 512);  // K weights: in flight during staging and LayerNorm
   stage_tile(xg, xn, HW, tid);
   // rows >= HW of the attention-output tile are padding for the out-projection: keep them finite
   for (int c = tid + HW * 16; c < kRows * 16; c += 256) *reinterpret_cast<uint4*>(ao + (c >> 4) * kStride + (c & 15) * 16) = make_uint4(0, 0, 0, 0);
@@ -135,32 +193,13 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   layernorm_rows(xn, HW, a.ln_g, a.ln_b, a.ln_eps, tid);
   __syncthreads();
 
-  const short8* wq = reinterpret_cast<const short8*>(a.wqkv) + (size_t)wave * 128 + lane;
   short8 Qf[8], Kf[8], VTf[4][2];
-  {  // ---- Q_w : lane ends with dims 8q4..8q4+7 of token (t*16 + l15)
-    float4v acc[8][2];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
-    gemm_k128_wA(acc, wq, xn, l15, q4);
-    float bias[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[wave * 32 + q4 * 8 + i];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[t][0][j] += bias[j];
-        acc[t][1][j] += bias[4 + j];
-      }
-      Qf[t] = pack8(acc[t][0], acc[t][1]);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
   {  // ---- K_w
     float4v acc[8][2];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
-    gemm_k128_wA(acc, wq + (size_t)4 * 512, xn, l15, q4);
+    load_wfrags(wb, wq + (size_t)8 * 512);  // V weights fly during the K GEMM
+    gemm_k128<false>(acc, wa, xn, l15, q4);
     float bias[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[kD + wave * 32 + q4 * 8 + i];
@@ -179,25 +218,8 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
     float4v acc[8][2];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
-    const short8* wv = wq + (size_t)8 * 512;
-    short8 b0 = wv[0], b1 = wv[64];
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      short8 nb0 = b0, nb1 = b1;
-      if (kc < 3) {
-        nb0 = wv[(kc + 1) * 512];
-        nb1 = wv[(kc + 1) * 512 + 64];
-      }
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const short8 xv = *reinterpret_cast<const short8*>(xn + (t * 16 + l15) * kStride + kc * 64 + q4 * 16);
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, b0, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, b1, acc[t][1], 0, 0, 0);
-      }
-      b0 = nb0;
-      b1 = nb1;
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    load_wfrags(wa, wq);  // Q weights fly during the V GEMM
+    gemm_k128<true>(acc, wb, xn, l15, q4);
     const int chp = (l15 >> 2) * 8 + (l15 & 3);
     const float bv0 = a.bqkv[2 * kD + wave * 32 + chp], bv1 = a.bqkv[2 * kD + wave * 32 + chp + 4];
 #pragma unroll
@@ -215,8 +237,28 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   }
 
   __builtin_amdgcn_sched_barrier(0);
+  {  // ---- Q_w : lane ends with dims 8q4..8q4+7 of token (t*16 + l15)
+    float4v acc[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+    gemm_k128<false>(acc, wa, xn, l15, q4);
+    float bias[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[wave * 32 + q4 * 8 + i];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[t][0][j] += bias[j];
+        acc[t][1][j] += bias[4 + j];
+      }
+      Qf[t] = pack8(acc[t][0], acc[t][1]);
+    }
+  }
+  load_wfrags(wb, reinterpret_cast<const short8*>(a.wo) + (size_t)wave * 128 + lane);  // out-proj weights fly during attention
   // ---- attention of head `wave`, one 16-query tile at a time
   const int n_qt = (HW + 15) >> 4;
+  const int kt_full = HW >> 4;  // key tiles below this index hold no padding
 #pragma unroll
   for (int qt = 0; qt < 8; ++qt) {
     if (qt >= n_qt) break;
@@ -226,11 +268,13 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
       st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt], Qf[qt], (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      if (kt >= kt_full) {  // wave-uniform: only the last (partial) key tile and the all-padding tiles pay for masking
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
-        m = fmaxf(m, st[kt][j]);
+        for (int j = 0; j < 4; ++j)
+          if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -239,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float p = __expf(st[kt][j] - m);
+        const float p = __builtin_amdgcn_exp2f(st[kt][j] - m);  // scores arrive in log2 units
         st[kt][j] = p;
         sum += p;
       }
@@ -264,11 +308,13 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   __syncthreads();
 
   // ---- output projection + residual
+  const int ch0 = wave * 32 + q4 * 8;
+  ResFrags res;
+  load_residual(res, xg + ch0, HW, l15);
   float4v acc[8][2];
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
-  gemm_k128_wA(acc, reinterpret_cast<const short8*>(a.wo) + (size_t)wave * 128 + lane, ao, l15, q4);
-  const int ch0 = wave * 32 + q4 * 8;
+  gemm_k128<false>(acc, wb, ao, l15, q4);
   float bias[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bias[i] = a.bo[ch0 + i];
@@ -278,12 +324,11 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
     int r = t * 16 + l15;
     asm volatile("" : "+v"(r));
     if (r >= HW) continue;
-    const short8 rv = *reinterpret_cast<const short8*>(xg + (size_t)r * kD + ch0);
     float o[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      o[j] = acc[t][0][j] + bias[j] + bf16_to_float((unsigned short)rv[j]);
-      o[4 + j] = acc[t][1][j] + bias[4 + j] + bf16_to_float((unsigned short)rv[4 + j]);
+      o[j] = acc[t][0][j] + bias[j] + bf16_to_float((unsigned short)res.r[t][j]);
+      o[4 + j] = acc[t][1][j] + bias[4 + j] + bf16_to_float((unsigned short)res.r[t][4 + j]);
     }
     *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
   }
@@ -302,6 +347,8 @@ struct FfnBlockArgs {
   float ln_eps;
 };
 
+// HALVES = F / 128 (compile time so that every prefetch below has a statically known live range).
+template <int HALVES>
 __global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* yn = smem;
@@ -312,6 +359,10 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
   const int HW = a.HW;
   const unsigned short* yg = a.y + (size_t)b * HW * kD;
 
+  const short8* w1p = reinterpret_cast<const short8*>(a.w1) + (size_t)wave * 128 + lane;
+  const short8* w2p = reinterpret_cast<const short8*>(a.w2) + (size_t)wave * 128 + lane;
+  WFrags wa, wb;
+  load_wfrags(wa, w1p);  // first W1 block: in flight during staging and LayerNorm
   stage_tile(yg, yn, HW, tid);
   __syncthreads();
   layernorm_rows(yn, HW, a.ln_g, a.ln_b, a.ln_eps, tid);
@@ -321,13 +372,17 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc_o[t][0] = acc_o[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
   const int ch0 = wave * 32 + q4 * 8;
-  const int halves = a.F >> 7;
+  constexpr int halves = HALVES;
+  ResFrags res;
+#pragma unroll
   for (int h = 0; h < halves; ++h) {
     {
       float4v acc_h[8][2];
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc_h[t][0] = acc_h[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
-      gemm_k128_wA(acc_h, reinterpret_cast<const short8*>(a.w1) + ((size_t)h * 4 * 4 + wave) * 128 + lane, yn, l15, q4);
+      load_wfrags(wb, w2p + (size_t)h * 4 * 512);  // this half's W2 steps fly during the first GEMM
+      gemm_k128<false>(acc_h, wa, yn, l15, q4);
+      if (h + 1 < halves) load_wfrags(wa, w1p + (size_t)(h + 1) * 4 * 512);  // next W1 block flies during the second GEMM
       float bias[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) bias[i] = a.b1[h * 128 + ch0 + i];
@@ -352,7 +407,8 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
       }
     }
     __syncthreads();
-    gemm_k128_wA(acc_o, reinterpret_cast<const short8*>(a.w2) + ((size_t)h * 4 * 4 + wave) * 128 + lane, hh, l15, q4);
+    if (h + 1 == halves) load_residual(res, yg + ch0, HW, l15);
+    gemm_k128<false>(acc_o, wb, hh, l15, q4);
   }
 
   float bias[8];
@@ -364,16 +420,28 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
     int r = t * 16 + l15;
     asm volatile("" : "+v"(r));
     if (r >= HW) continue;
-    const short8 rv = *reinterpret_cast<const short8*>(yg + (size_t)r * kD + ch0);
     float o[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      o[j] = acc_o[t][0][j] + bias[j] + bf16_to_float((unsigned short)rv[j]);
-      o[4 + j] = acc_o[t][1][j] + bias[4 + j] + bf16_to_float((unsigned short)rv[4 + j]);
+      o[j] = acc_o[t][0][j] + bias[j] + bf16_to_float((unsigned short)res.r[t][j]);
+      o[4 + j] = acc_o[t][1][j] + bias[4 + j] + bf16_to_float((unsigned short)res.r[t][4 + j]);
     }
     *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
   }
 }
+
+namespace {
+template <int HALVES>
+int launch_ffn(const FfnBlockArgs& a, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)ffn_block_kernel<HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
+    attr = true;
+  }
+  hipLaunchKernelGGL(ffn_block_kernel<HALVES>, dim3(a.B), dim3(256), 2 * kTileBytes, stream, a);
+  return (int)hipGetLastError();
+}
+}  // namespace
 
 extern "C" {
 
@@ -399,15 +467,15 @@ int atri_ffn_block(const void* y, void* out, const void* w1, const float* b1, co
   if (B <= 0) return 0;
   if (D != kD || (F & 127) != 0 || F < 128 || HW > kRows || HW < 1) return -10;
   if (act != kActReLU && act != kActGELU) return -11;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)ffn_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
-    attr = true;
-  }
   FfnBlockArgs a{(const unsigned short*)y, (unsigned short*)out, (const unsigned short*)w1, b1,
                  (const unsigned short*)w2, b2, ln_g, ln_b, B, HW, F, act, ln_eps};
-  hipLaunchKernelGGL(ffn_block_kernel, dim3(B), dim3(256), 2 * kTileBytes, stream, a);
-  return (int)hipGetLastError();
+  switch (F >> 7) {
+    case 1: return launch_ffn<1>(a, stream);
+    case 2: return launch_ffn<2>(a, stream);
+    case 3: return launch_ffn<3>(a, stream);
+    case 4: return launch_ffn<4>(a, stream);
+    default: return -12;
+  }
 }
 
 }  // extern "C"

@@ -292,8 +292,9 @@ class InferenceEngine:
             for layer in model.transformer_body.layers:
                 w_in = layer.self_attn.in_proj_weight.detach().float().clone()  # [3D, D]
                 b_in = layer.self_attn.in_proj_bias.detach().float().clone()
-                w_in[:D] *= 1.0 / math.sqrt(hd)
-                b_in[:D] *= 1.0 / math.sqrt(hd)
+                qscale = math.log2(math.e) / math.sqrt(hd)  # the kernels' softmax is exp2-based
+                w_in[:D] *= qscale
+                b_in[:D] *= qscale
                 qkv = self._gemm(
                     w_in.t().unsqueeze(0).contiguous(), b_in, 0,
                     ln_g=layer.norm1.weight.detach().float().to(dev), ln_b=layer.norm1.bias.detach().float().to(dev),

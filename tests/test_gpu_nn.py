@@ -109,7 +109,9 @@ def test_attention_matches_torch():
     def sh(t):
         return t.view(B, HW, heads, 32).permute(0, 2, 1, 3)
 
-    ref = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), scale=1.0).permute(0, 2, 1, 3).reshape(B, HW, D)
+    # the kernel's softmax is exp2-based (the engine folds log2(e) into the Q projection)
+    probs = torch.softmax(sh(q) @ sh(k).transpose(-1, -2) * math.log(2.0), dim=-1)
+    ref = (probs @ sh(v)).permute(0, 2, 1, 3).reshape(B, HW, D)
     out = torch.zeros(B, HW, D, dtype=torch.bfloat16, device=dev)
     hb.call("atri_attention", hb.ptr(qkv.to(torch.bfloat16).contiguous()), hb.ptr(out), hb.i32(B), hb.i32(HW), hb.i32(D), hb.i32(heads))
     torch.cuda.synchronize()
@@ -180,8 +182,8 @@ def test_fused_encoder_layer_matches_torch(hw, act_name):
 
     w_in = layer.self_attn.in_proj_weight.detach().float().clone()
     b_in = layer.self_attn.in_proj_bias.detach().float().clone()
-    w_in[:D] *= 1.0 / math.sqrt(32)
-    b_in[:D] *= 1.0 / math.sqrt(32)
+    w_in[:D] *= math.log2(math.e) / math.sqrt(32)  # the kernels' softmax is exp2-based
+    b_in[:D] *= math.log2(math.e) / math.sqrt(32)
     xb = x.to(torch.bfloat16).contiguous()
     y = torch.zeros_like(xb)
     z = torch.zeros_like(xb)
