@@ -100,7 +100,50 @@ __device__ void wave_features(const GeomView& g, const State& st, float* grid, f
 }
 
 // Masked softmax of the network logits over the valid actions (wave order) -> fresh edges.
+// For action spaces up to 6 x 64 the per-lane validity bits and exponentials are computed once and kept
+// in registers across the max / sum / write passes (the arithmetic and its order are unchanged).
+constexpr int kLaneActs = 6;
 __device__ void wave_init_edges(const GeomView& g, const State& st, Edge* ed, const float* logits, int lane) {
+  if (g.action_dim <= kLaneActs * 64) {
+    float lg[kLaneActs];
+    unsigned vbits = 0;
+#pragma unroll
+    for (int k = 0; k < kLaneActs; ++k) {
+      const int a = lane + 64 * k;
+      lg[k] = 0.0f;
+      if (a < g.action_dim && action_valid(g, st, a)) {
+        vbits |= 1u << k;
+        lg[k] = logits[a];
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kLaneActs; ++k)
+      if (vbits & (1u << k)) mx = fmaxf(mx, lg[k]);
+    mx = atrihip::wave_max(mx);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kLaneActs; ++k)
+      if (vbits & (1u << k)) {
+        lg[k] = exp_det(lg[k] - mx);
+        s = s + lg[k];
+      }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+#pragma unroll
+    for (int k = 0; k < kLaneActs; ++k) {
+      const int a = lane + 64 * k;
+      if (a < g.action_dim) {
+        Edge e;
+        e.prior = (vbits & (1u << k)) ? lg[k] / s : -1.0f;
+        e.n = 0;
+        e.w = 0.0f;
+        e.child = -1;
+        ed[a] = e;
+      }
+    }
+    return;
+  }
   float mx = -INFINITY;
   for (int a = lane; a < g.action_dim; a += 64)
     if (action_valid(g, st, a)) mx = fmaxf(mx, logits[a]);
@@ -120,12 +163,35 @@ __device__ void wave_init_edges(const GeomView& g, const State& st, Edge* ed, co
   }
 }
 
-__device__ int wave_select_action(const Edge* ed, const NodeMeta& m, int A, const SearchParams& sp, int lane) {
+// PUCT argmax over a node's edges: lanes stride over the dense edge array, xor-butterfly reduction with
+// lowest-action tie break.  `pre` holds this lane's first kLaneActs edges when the caller loaded them
+// ahead of time (together with the node's meta, so the two HBM round trips overlap); the child index of
+// the winning edge travels through the reduction so the caller needs no second load.
+struct Pick {
+  int action, child;
+};
+template <bool PRE>
+__device__ __forceinline__ Pick wave_select_action(const Edge* ed, const Edge (&pre)[kLaneActs], const NodeMeta& m, int A,
+                                                   const SearchParams& sp, int lane) {
   const float sqrt_parent = sqrtf((float)(m.n > 1 ? m.n : 1));
   const float fpu = (sp.fpu_parent && m.n > 0) ? m.w / (float)m.n : 0.0f;
   float bs = -INFINITY;
-  int ba = 0x7FFFFFFF;
-  for (int a = lane; a < A; a += 64) {
+  int ba = 0x7FFFFFFF, bc = -1;
+  if (PRE) {
+#pragma unroll
+    for (int k = 0; k < kLaneActs; ++k) {
+      const Edge e = pre[k];
+      if (e.prior < 0.0f) continue;
+      float q = e.n > 0 ? e.w / (float)e.n : fpu;
+      float sc = puct_score(q, e.prior, sqrt_parent, e.n, sp.cpuct);
+      if (sc > bs) {
+        bs = sc;
+        ba = lane + 64 * k;
+        bc = e.child;
+      }
+    }
+  }
+  for (int a = lane + (PRE ? kLaneActs * 64 : 0); a < A; a += 64) {
     Edge e = ed[a];
     if (e.prior < 0.0f) continue;
     float q = e.n > 0 ? e.w / (float)e.n : fpu;
@@ -133,18 +199,24 @@ __device__ int wave_select_action(const Edge* ed, const NodeMeta& m, int A, cons
     if (sc > bs) {
       bs = sc;
       ba = a;
+      bc = e.child;
     }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     float os = __shfl_xor(bs, off, 64);
     int oa = __shfl_xor(ba, off, 64);
+    int oc = __shfl_xor(bc, off, 64);
     if (os > bs || (os == bs && oa < ba)) {
       bs = os;
       ba = oa;
+      bc = oc;
     }
   }
-  return ba == 0x7FFFFFFF ? -1 : ba;
+  Pick p;
+  p.action = ba == 0x7FFFFFFF ? -1 : ba;
+  p.child = bc;
+  return p;
 }
 
 // ------------------------------------------------------------------ batched engine ops (parity tests, resets)
@@ -324,30 +396,46 @@ __global__ void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int d
         value = meta[leaf].nn_value;
       }
       __syncthreads();
+      // Backup.  Lane i owns path step i: its loads and read-modify-writes touch a node no other lane touches,
+      // so the whole path costs one memory round trip instead of one per level.  The discounted return is the
+      // same left-to-right float recurrence as the host search, run in registers over shuffled rewards.
+      const int plen = tb.slot_plen[slot];
+      const int32_t* pn = tb.path_node + (size_t)slot * tb.P;
+      const int32_t* pa = tb.path_action + (size_t)slot * tb.P;
+      int node_i = 0, act_i = 0;
+      float r_i = 0.0f;
+      if (lane < plen) {
+        node_i = pn[lane];
+        act_i = pa[lane];
+        const int child_i = (lane + 1 < plen) ? pn[lane + 1] : leaf;
+        r_i = meta[child_i].reward;
+      }
+      float ret = value, my_ret = 0.0f;
+      for (int i = plen - 1; i >= 0; --i) {
+        ret = __shfl(r_i, i, 64) + sp.discount * ret;
+        if (lane == i) my_ret = ret;
+      }
+      if (lane < plen) {
+        Edge* e = edges + (size_t)node_i * A + act_i;
+        Edge ev = *e;
+        if (vl) {
+          ev.w = ev.w - sp.virtual_loss;
+        } else {
+          ev.n += 1;
+        }
+        ev.w = ev.w + my_ret;
+        *e = ev;
+        NodeMeta* mp = meta + node_i;
+        mp->n += 1;
+        mp->w = mp->w + my_ret;
+      }
       if (lane == 0) {
         if (kind == kSlotExpand) {
           meta[leaf].expanded = 1;
           meta[leaf].nn_value = value;
         }
-        float ret = value;
         meta[leaf].n += 1;
-        meta[leaf].w = meta[leaf].w + ret;
-        const int plen = tb.slot_plen[slot];
-        const int32_t* pn = tb.path_node + (size_t)slot * tb.P;
-        const int32_t* pa = tb.path_action + (size_t)slot * tb.P;
-        for (int i = plen - 1; i >= 0; --i) {
-          const int node = pn[i];
-          Edge* e = edges + (size_t)node * A + pa[i];
-          ret = meta[e->child].reward + sp.discount * ret;
-          if (vl) {
-            e->w = e->w - sp.virtual_loss;
-          } else {
-            e->n += 1;
-          }
-          e->w = e->w + ret;
-          meta[node].n += 1;
-          meta[node].w = meta[node].w + ret;
-        }
+        meta[leaf].w = meta[leaf].w + value;
         tb.slot_kind[slot] = kSlotNone;
       }
       __syncthreads();
@@ -360,7 +448,22 @@ __global__ void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int d
     int32_t* pn = tb.path_node + (size_t)slot * tb.P;
     int32_t* pa = tb.path_action + (size_t)slot * tb.P;
     int node = 0, depth = 0, plen = 0, kind = kSlotNone, leaf = -1;
+    const bool pre_ok = A <= kLaneActs * 64;
     while (true) {
+      // the lane's edges are requested together with the node's meta (one HBM round trip per level)
+      Edge pre[kLaneActs];
+      if (pre_ok) {
+        const Edge* ed = edges + (size_t)node * A;
+#pragma unroll
+        for (int k = 0; k < kLaneActs; ++k) {
+          const int a = lane + 64 * k;
+          pre[k].prior = -1.0f;
+          pre[k].n = 0;
+          pre[k].w = 0.0f;
+          pre[k].child = -1;
+          if (a < A) pre[k] = ed[a];
+        }
+      }
       const NodeMeta m = meta[node];
       if (m.terminal) {
         kind = kSlotTerminal;
@@ -383,14 +486,16 @@ __global__ void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int d
         leaf = node;
         break;
       }
-      const int a = wave_select_action(edges + (size_t)node * A, m, A, sp, lane);
+      const Pick pick = pre_ok ? wave_select_action<true>(edges + (size_t)node * A, pre, m, A, sp, lane)
+                               : wave_select_action<false>(edges + (size_t)node * A, pre, m, A, sp, lane);
+      const int a = pick.action;
       if (a < 0) {
         kind = kSlotDepthCap;
         leaf = node;
         break;
       }
       Edge* e = edges + (size_t)node * A + a;
-      const int child = e->child;
+      const int child = pick.child;
       const int nn = tb.n_nodes[t];
       if (child < 0 && nn >= tb.C) {
         kind = kSlotDepthCap;
