@@ -29,6 +29,11 @@ class SystemConfig(BaseModel):
     REPLAY_ON_DEVICE: bool = Field(default=True, description="Keep the replay buffer in HBM on GPU runs.")
     REPLAY_HBM_BUDGET_GB: float = Field(default=64.0, gt=0)
     TRAIN_STEPS_PER_MOVE: int = Field(default=1, ge=0, description="Learner steps interleaved per self-play move.")
+    TRAIN_STEPS_PER_ROUND: int = Field(
+        default=32, ge=0,
+        description="Split layout: learner steps per lock-step round (one round = one self-play move on every actor rank).",
+    )
+    SHIP_CAPACITY: int = Field(default=1 << 15, ge=1, description="Split layout: experience records per actor per round (fixed block).")
     USE_HIP_GRAPHS: bool = Field(default=True)
     WEIGHT_SYNC_ASYNC: bool = Field(default=True)
     DIST_BACKEND: Literal["auto", "nccl", "gloo"] = Field(default="auto", description="nccl = RCCL on ROCm.")

@@ -66,6 +66,8 @@ class DistContext:
     layout: RoleLayout
     learner_group: Any = None
     world_group: Any = None
+    cohort_group: Any = None          # split layout: one learner + the actors that feed it
+    cohort_ranks: list[int] = field(default_factory=list)
     owns_process_group: bool = True
     _side_stream: Any = field(default=None, repr=False)
     _pending_weight_work: Any = field(default=None, repr=False)
@@ -152,6 +154,30 @@ class DistContext:
         dist.all_gather_into_tensor(out.view(-1), block.contiguous().view(-1), group=self.world_group)
         return out
 
+    def gather_blocks_to_learner(self, block: torch.Tensor) -> list[torch.Tensor] | None:
+        """Split layout: gather equally sized blocks from this rank's cohort onto its learner.
+
+        Returns the per-cohort-member list (cohort order, the learner's own block first) on the
+        learner and ``None`` on actors.  Point-to-point under the hood: only the learner receives,
+        so actor GPUs spend no xGMI bandwidth on each other's experiences.
+        """
+        if self.layout.colocated or self.cohort_group is None:
+            raise RuntimeError("gather_blocks_to_learner needs the split role layout")
+        dst = self.cohort_ranks[0]
+        staged = self._host_staged() and block.is_cuda
+        send = block.detach().to("cpu", non_blocking=False).contiguous() if staged else block.contiguous()
+        if self.rank == dst:
+            outs = [torch.empty_like(send) for _ in self.cohort_ranks]
+            dist.gather(send, gather_list=outs, dst=dst, group=self.cohort_group)
+            return [o.to(block.device, non_blocking=False) for o in outs] if staged else outs
+        dist.gather(send, gather_list=None, dst=dst, group=self.cohort_group)
+        return None
+
+    def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place MAX all-reduce of a small control tensor over every rank."""
+        self._collective(dist.all_reduce, t, op=dist.ReduceOp.MAX, group=self.world_group)
+        return t
+
     def all_reduce_scalar(self, value: float, op: str = "sum") -> float:
         t = torch.tensor([float(value)], dtype=torch.float64)
         if not self._host_staged():
@@ -214,6 +240,14 @@ def init_distributed(
     roles = RoleLayout.build(world_size, layout, num_learners)
     # new_group must be called by every rank, in the same order
     learner_group = dist.new_group(ranks=roles.learner_ranks) if len(roles.learner_ranks) < world_size else None
+    cohort_group, cohort_ranks = None, []
+    if not roles.colocated:
+        n_l = len(roles.learner_ranks)
+        for li, lr in enumerate(roles.learner_ranks):
+            members = [lr] + [a for ai, a in enumerate(roles.actor_ranks) if ai % n_l == li]
+            grp = dist.new_group(ranks=members)  # every rank creates every cohort group, in the same order
+            if rank in members:
+                cohort_group, cohort_ranks = grp, members
     ctx = DistContext(
         rank=rank,
         world_size=world_size,
@@ -223,6 +257,8 @@ def init_distributed(
         layout=roles,
         learner_group=learner_group,
         world_group=None,
+        cohort_group=cohort_group,
+        cohort_ranks=cohort_ranks,
         owns_process_group=owns,
     )
     logger.info(

@@ -3,10 +3,11 @@
 The reference returns pickled ``SelfPlayResult`` objects through Ray's object store
 (alphatriangle/training/worker_manager.py:117-134); each experience carries a dense
 360-entry Python dict.  Here an experience is one fixed-stride fp32 record
-``[grid | other | policy | return]`` and a shipment is ONE all-gather of equally sized
-record blocks per round: every rank contributes ``[capacity + 1, stride]`` (row 0 holds
-the live count), learners keep the blocks of the actors assigned to them.  Fixed sizes
-keep the collective graph-capturable and free of host-side size negotiation.
+``[grid | other | policy | return]`` and a shipment is ONE gather of equally sized record
+blocks per round onto each learner from the actors assigned to it (split layout; only the
+learner receives, so actor GPUs spend no xGMI bandwidth on each other's data).  Every rank
+contributes ``[capacity + 1, stride]`` (row 0 holds the live count).  Fixed sizes keep the
+collective free of host-side size negotiation.
 """
 
 from __future__ import annotations
@@ -63,6 +64,18 @@ class ExperienceShipper:
             self.dropped += int(records.shape[0]) - n
             self.block[1 : 1 + n].copy_(records[:n].to(self.device))
         self.block[0, 0] = float(n)
+        if not self.ctx.layout.colocated and self.ctx.cohort_group is not None:
+            blocks = self.ctx.gather_blocks_to_learner(self.block)
+            if blocks is None:
+                return torch.empty(0, self.layout.stride, dtype=torch.float32, device=self.device)
+            parts = []
+            for blk in blocks[1:]:  # [0] is the learner's own (empty) block
+                cnt = int(blk[0, 0].item())
+                if cnt > 0:
+                    parts.append(blk[1 : 1 + cnt].to(self.device))
+            if not parts:
+                return torch.empty(0, self.layout.stride, dtype=torch.float32, device=self.device)
+            return torch.cat(parts, dim=0)
         gathered = self.ctx.all_gather_records(self.block)  # [world, cap+1, stride]
         if not self.ctx.is_learner:
             return torch.empty(0, self.layout.stride, dtype=torch.float32, device=self.device)

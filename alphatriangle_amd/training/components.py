@@ -15,7 +15,7 @@ from ..stats import Serializer, StatsActor, TrieyeConfig
 class TrainingComponents:
     nn: NeuralNetwork
     buffer: Any  # ExperienceBuffer (host) or DeviceReplayBuffer (HBM)
-    trainer: Trainer
+    trainer: Trainer | None    # None on pure actor ranks of the split role layout
     trieye_actor: StatsActor
     trieye_config: TrieyeConfig
     serializer: Serializer
@@ -27,3 +27,4 @@ class TrainingComponents:
     system_config: SystemConfig = field(default_factory=SystemConfig)
     gpu_actor: Any = None      # GpuSelfPlayActor when the HBM-resident engine is active
     dist: Any = None           # parallel.DistContext for multi-GPU runs
+    experience_source: Any = None  # split layout, actor ranks: what produces this rank's experience records

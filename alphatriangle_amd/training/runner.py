@@ -20,7 +20,13 @@ logger = logging.getLogger(__name__)
 def _load_and_apply_initial_state(components: TrainingComponents) -> TrainingLoop:
     """Load checkpoint / buffer through the stats actor and apply them to the components."""
     loaded = components.trieye_actor.load_initial_state()
-    loop = TrainingLoop(components)
+    loop: TrainingLoop
+    if components.dist is not None and not components.dist.layout.colocated:
+        from .split_loop import SplitRoleLoop
+
+        loop = SplitRoleLoop(components, components.experience_source)
+    else:
+        loop = TrainingLoop(components)
     ckpt = loaded.checkpoint_data
     if ckpt is not None:
         logger.info("Applying loaded checkpoint data (Run: %s, Step: %d)", ckpt.run_name, ckpt.global_step)
@@ -28,7 +34,8 @@ def _load_and_apply_initial_state(components: TrainingComponents) -> TrainingLoo
             components.nn.set_weights(ckpt.model_state_dict)
         if ckpt.optimizer_state_dict:
             try:
-                components.trainer.load_optimizer_state(ckpt.optimizer_state_dict)
+                if components.trainer is not None:
+                    components.trainer.load_optimizer_state(ckpt.optimizer_state_dict)
                 logger.info("Optimizer state loaded and moved to device.")
             except Exception as exc:
                 logger.error("Could not load optimizer state: %s. Optimizer might reset.", exc)
@@ -61,7 +68,7 @@ def _save_final_state(loop: TrainingLoop) -> None:
         buffer_data = loop.serializer.prepare_buffer_data(comps.buffer) if save_buffer else None
         actor.save_training_state(
             nn_state_dict=comps.nn.get_weights(),
-            optimizer_state_dict=loop.serializer.prepare_optimizer_state(comps.trainer.optimizer.state_dict()),
+            optimizer_state_dict=loop.serializer.prepare_optimizer_state(comps.trainer.optimizer.state_dict()) if comps.trainer is not None else {},
             buffer_content=buffer_data.buffer_list if buffer_data else [],
             global_step=loop.global_step,
             episodes_played=loop.episodes_played,

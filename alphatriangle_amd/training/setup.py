@@ -87,7 +87,12 @@ def setup_training_components(
         neural_net = NeuralNetwork(model_config, env_config, train_config, device)
 
         use_gpu_engine = system_config.ENGINE == "gpu" or (system_config.ENGINE == "auto" and device.type == "cuda")
+        split = dist_context is not None and not dist_context.layout.colocated
+        pure_actor = split and not dist_context.is_learner
+        pure_learner = split and not dist_context.is_actor
+        rank = dist_context.rank if dist_context else 0
         gpu_actor = None
+        experience_source = None
         buffer: Any
         if use_gpu_engine:
             if device.type != "cuda":
@@ -95,23 +100,58 @@ def setup_training_components(
             from ..rl.core.device_buffer import DeviceReplayBuffer
             from ..rl.self_play.gpu_actor import GpuSelfPlayActor
 
-            buffer = DeviceReplayBuffer(train_config, env_config, model_config, device, system_config)
-            gpu_actor = GpuSelfPlayActor(
-                env_config, model_config, mcts_config, train_config, system_config, neural_net, buffer, device,
-                seed=train_config.RANDOM_SEED + (dist_context.rank if dist_context else 0) * 1_000_003,
-            )
+            buf_cfg = train_config
+            if pure_actor:
+                # actor ranks keep only an outbox: one move's worth of experiences, shipped every round
+                cap = max(int(system_config.SHIP_CAPACITY), system_config.GAMES_PER_GPU * (train_config.N_STEP_RETURNS + 1))
+                buf_cfg = train_config.model_copy(
+                    update={"BUFFER_CAPACITY": cap, "MIN_BUFFER_SIZE_TO_TRAIN": 1, "BATCH_SIZE": 1, "USE_PER": False}
+                )
+            buffer = DeviceReplayBuffer(buf_cfg, env_config, model_config, device, system_config)
+            if not pure_learner:
+                gpu_actor = GpuSelfPlayActor(
+                    env_config, model_config, mcts_config, train_config, system_config, neural_net, buffer, device,
+                    seed=train_config.RANDOM_SEED + rank * 1_000_003,
+                )
         else:
             buffer = ExperienceBuffer(train_config)
+        if pure_actor:
+            from ..parallel.experience import RecordLayout
+            from .split_loop import GpuExperienceSource, HostExperienceSource
 
-        grad_sync = dist_context.grad_sync if dist_context is not None and dist_context.world_size > 1 else None
-        trainer = Trainer(
-            neural_net,
-            train_config,
-            env_config,
-            autocast_bf16=system_config.LEARNER_AUTOCAST,
-            grad_sync=grad_sync,
-            world_size=dist_context.world_size if dist_context is not None else 1,
-        )
+            layout = RecordLayout(
+                model_config.GRID_INPUT_CHANNELS * env_config.ROWS * env_config.COLS,
+                model_config.OTHER_NN_INPUT_FEATURES_DIM,
+                env_config.ACTION_DIM,
+            )
+            if gpu_actor is not None:
+                experience_source = GpuExperienceSource(gpu_actor, buffer, layout)
+            else:
+                from ..rl.self_play.worker import SelfPlayWorker
+
+                worker = SelfPlayWorker(
+                    rank, env_config, mcts_config, model_config, train_config, stats_actor=stats_actor,
+                    run_base_dir=stats_actor.get_run_base_dir_str(), seed=train_config.RANDOM_SEED + rank,
+                    worker_device_str=train_config.WORKER_DEVICE,
+                )
+                worker.nn_evaluator = neural_net  # published weights land in this rank's network
+                experience_source = HostExperienceSource(worker, layout, env_config.ACTION_DIM)
+
+        trainer = None
+        if not pure_actor:
+            n_sync = 1
+            grad_sync = None
+            if dist_context is not None and dist_context.world_size > 1:
+                n_sync = dist_context.num_learners if split else dist_context.world_size
+                grad_sync = dist_context.grad_sync if n_sync > 1 else None
+            trainer = Trainer(
+                neural_net,
+                train_config,
+                env_config,
+                autocast_bf16=system_config.LEARNER_AUTOCAST,
+                grad_sync=grad_sync,
+                world_size=n_sync,
+            )
         components = TrainingComponents(
             nn=neural_net,
             buffer=buffer,
@@ -127,6 +167,7 @@ def setup_training_components(
             system_config=system_config,
             gpu_actor=gpu_actor,
             dist=dist_context,
+            experience_source=experience_source,
         )
         return components, started
     except Exception as exc:

@@ -136,3 +136,34 @@ def test_role_layout():
     c = RoleLayout.build(4, "colocated", 1)
     assert c.learner_ranks == c.actor_ranks == [0, 1, 2, 3] and c.colocated
     assert RoleLayout.build(1, "split", 1).colocated
+
+
+def _split_training(rank, world, init, root):
+    """One learner + two host actors run the real split-role loop end to end (tiny world, gloo)."""
+    from alphatriangle_amd.config import AlphaTriangleMCTSConfig, SystemConfig
+    from alphatriangle_amd.stats import TrieyeConfig
+    from alphatriangle_amd.training.runner import run_training
+
+    torch.set_num_threads(1)
+    ctx = init_distributed(rank, world, rank, backend="gloo", layout="split", num_learners=1, init_method=init, timeout_s=120)
+    env, mc, tc = _tiny_cfg()
+    tc = tc.model_copy(update={"MAX_TRAINING_STEPS": 6, "WORKER_UPDATE_FREQ_STEPS": 2, "CHECKPOINT_SAVE_FREQ_STEPS": 4,
+                               "NUM_SELF_PLAY_WORKERS": 1, "N_STEP_RETURNS": 2, "AUTO_RESUME_LATEST": False})
+    sysc = SystemConfig(ENGINE="cpu", ROLE_LAYOUT="split", NUM_LEARNER_RANKS=1, TRAIN_STEPS_PER_ROUND=2, SHIP_CAPACITY=64, DIST_BACKEND="gloo")
+    mcts = AlphaTriangleMCTSConfig(max_simulations=4, max_depth=3, mcts_batch_size=2)
+    run = "split" if rank == 0 else f"split_rank{rank}"
+    tcfg = TrieyeConfig(app_name="t", run_name=run)
+    tcfg.persistence.ROOT_DATA_DIR = root
+    tcfg.persistence.RUN_NAME = run
+    code = run_training("WARNING", tc, tcfg, False, model_config_override=mc, mcts_config_override=mcts, env_config_override=env,
+                        system_config_override=sysc, dist_context=ctx)
+    assert code == 0, f"rank {rank} exited with {code}"
+    if rank == 0:
+        ckpts = [f for _, _, fs in os.walk(os.path.join(root, "t", "runs", "split", "checkpoints")) for f in fs]
+        assert any(f.endswith(".pkl") for f in ckpts), "the lead learner must have written a checkpoint"
+    ctx.shutdown()
+
+
+def test_split_role_training_loop_three_ranks():
+    with tempfile.TemporaryDirectory() as root:
+        _spawn(_split_training, 3, root)
