@@ -27,7 +27,7 @@ def _rank_main(rank, world, init, root):
     ctx = init_distributed(rank, world, 0, backend="gloo", layout="split", num_learners=1, init_method=init, timeout_s=180)
     env, mc = EnvConfig(), ModelConfig()
     tc = TrainConfig(DEVICE="cuda", BATCH_SIZE=64, BUFFER_CAPACITY=20_000, MIN_BUFFER_SIZE_TO_TRAIN=256, MAX_TRAINING_STEPS=8,
-                     WORKER_UPDATE_FREQ_STEPS=4, CHECKPOINT_SAVE_FREQ_STEPS=0, N_STEP_RETURNS=2, AUTO_RESUME_LATEST=False)
+                     WORKER_UPDATE_FREQ_STEPS=4, CHECKPOINT_SAVE_FREQ_STEPS=1000, N_STEP_RETURNS=2, AUTO_RESUME_LATEST=False)
     sysc = SystemConfig(ENGINE="gpu", ROLE_LAYOUT="split", NUM_LEARNER_RANKS=1, TRAIN_STEPS_PER_ROUND=4, SHIP_CAPACITY=1024,
                         GAMES_PER_GPU=128, DIST_BACKEND="gloo", REPLAY_HBM_BUDGET_GB=4.0)
     mcts = AlphaTriangleMCTSConfig(max_simulations=8, max_depth=4)
