@@ -77,6 +77,9 @@ def train(
     workers: Annotated[int | None, typer.Option(help="CPU self-play workers (cpu engine).")] = None,
     preset: Annotated[str, typer.Option(help="Config preset: default, cnn, tiny, large.")] = "default",
     data_root: Annotated[str | None, typer.Option(help="Root directory for run data (default .trieye_data).")] = None,
+    layout: Annotated[str, typer.Option(help="Multi-GPU role layout: colocated (every rank plays and learns) or split (actor ranks + learner ranks).")] = "colocated",
+    learners: Annotated[int, typer.Option(help="Learner ranks of the split layout (the rest self-play).")] = 1,
+    train_steps_per_round: Annotated[int | None, typer.Option(help="Split layout: learner steps per self-play move round.")] = None,
 ) -> None:
     """Run the headless training pipeline (one process per GPU; launch under torchrun for several GPUs)."""
     from .parallel.dist import init_from_env
@@ -96,6 +99,12 @@ def train(
     sys_cfg.ENGINE = engine  # type: ignore[assignment]
     if games_per_gpu is not None:
         sys_cfg.GAMES_PER_GPU = games_per_gpu
+    if layout not in ("colocated", "split"):
+        raise typer.BadParameter("--layout must be 'colocated' or 'split'")
+    sys_cfg.ROLE_LAYOUT = layout  # type: ignore[assignment]
+    sys_cfg.NUM_LEARNER_RANKS = learners
+    if train_steps_per_round is not None:
+        sys_cfg.TRAIN_STEPS_PER_ROUND = train_steps_per_round
 
     trieye_cfg = TrieyeConfig(app_name=APP_NAME, run_name=run_name or train_cfg.RUN_NAME)
     train_cfg.RUN_NAME = trieye_cfg.run_name
