@@ -81,8 +81,6 @@ def engine_supports(mc: ModelConfig, ec: EnvConfig) -> tuple[bool, str]:
     for w in [*mc.FC_DIMS_SHARED, *mc.POLICY_HEAD_DIMS, *mc.VALUE_HEAD_DIMS]:
         if not (_pow2(w) and 32 <= w <= 512):
             return False, f"dense width {w} must be a power of two in [32, 512]"
-    if (ec.NUM_SHAPE_SLOTS * hw) % 8 != 0:
-        return False, "action_dim must be a multiple of 8"
     return True, ""
 
 
@@ -200,7 +198,7 @@ class InferenceEngine:
         if self.rows_per_wg > 240 and self.HW <= 240:
             self.rows_per_wg = (240 // self.HW) * self.HW
         self.uses_tf = bool(model_config.USE_TRANSFORMER and model_config.TRANSFORMER_LAYERS > 0)
-        self.logit_stride = self.A
+        self.logit_stride = (self.A + 7) // 8 * 8  # rows padded so the 8-channel output groups never straddle rows
         self.value_stride = (model_config.NUM_VALUE_ATOMS + 7) // 8 * 8
         self.cap = 0
         self.loaded = False

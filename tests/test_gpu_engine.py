@@ -80,9 +80,9 @@ class _SyntheticNet:
         return logits.astype(np.float32), values.astype(np.float32)
 
 
-@pytest.mark.parametrize("leaves", [1, 3])
-def test_tree_search_equals_host_search(leaves):
-    env = EnvConfig()
+@pytest.mark.parametrize("leaves,large", [(1, False), (3, False), (1, True)])
+def test_tree_search_equals_host_search(leaves, large):
+    env = EnvConfig.large() if large else EnvConfig()  # the large board (756 actions) takes the strided edge-scan path
     sims = 48
     mcts = AlphaTriangleMCTSConfig(max_simulations=sims, max_depth=6, dirichlet_epsilon=0.0, mcts_batch_size=leaves)
     G = 6
@@ -193,3 +193,31 @@ def test_graph_replay_equals_eager():
             return torch.sort(h).values
 
         assert torch.allclose(signature(r1), signature(r2), atol=0, rtol=0)
+
+
+def test_large_preset_play_move():
+    """12x21 board, 8-layer encoder: generic tile kernel (MT=16), unfused attention (16 key tiles), 756 actions."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.presets import build_preset
+    from alphatriangle_amd.rl.core.device_buffer import DeviceReplayBuffer
+    from alphatriangle_amd.rl.self_play.gpu_actor import GpuSelfPlayActor
+
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    env, mc, _, _, _ = build_preset("large")
+    tc = TrainConfig(DEVICE="cuda", BUFFER_CAPACITY=5000, MIN_BUFFER_SIZE_TO_TRAIN=64, BATCH_SIZE=32, N_STEP_RETURNS=2, MAX_TRAINING_STEPS=1000)
+    sc = SystemConfig(GAMES_PER_GPU=24, REPLAY_HBM_BUDGET_GB=4.0)
+    mcts = AlphaTriangleMCTSConfig(max_simulations=10, max_depth=5)
+    net = NeuralNetwork(mc, env, tc, dev)
+    assert net.engine is not None and not net.engine.fused_tf
+    replay = DeviceReplayBuffer(tc, env, mc, dev, sc)
+    actor = GpuSelfPlayActor(env, mc, mcts, tc, sc, net, replay, dev, seed=3)
+    added = 0
+    for _ in range(4):
+        rep = actor.play_move()
+        assert rep.moves == actor.G and rep.simulations >= actor.G * 10
+        added += rep.experiences_added
+    assert added >= actor.G and len(replay) == added
+    pol = replay.policy[:added]
+    assert pol.shape[1] == env.ACTION_DIM
+    assert torch.allclose(pol.sum(1), torch.ones(added, device=dev), atol=1e-4)

@@ -119,14 +119,14 @@ def test_attention_matches_torch():
     assert err < 0.03, f"max err {err}"
 
 
-@pytest.mark.parametrize("preset", ["default", "cnn"])
+@pytest.mark.parametrize("preset", ["default", "cnn", "large"])
 def test_engine_forward_matches_pytorch_module(preset):
     from alphatriangle_amd.models.network import NeuralNetwork
 
     torch.manual_seed(3)
     dev = _dev()
-    env = EnvConfig()
-    mc = ModelConfig() if preset == "default" else ModelConfig.cnn_only()
+    env = EnvConfig.large() if preset == "large" else EnvConfig()
+    mc = {"default": ModelConfig(), "cnn": ModelConfig.cnn_only(), "large": ModelConfig.large_transformer()}[preset]
     net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev)
     assert net.engine is not None, "HIP engine must be active on the GPU box"
     # non-trivial BatchNorm statistics so the folding is really tested
