@@ -498,6 +498,109 @@ __global__ __launch_bounds__(256, 2) void fc_splitk_kernel(const unsigned short*
   }
 }
 
+// Shared FC fed directly by the body's NHWC rows (128 channels per pixel): the flatten is free (a sample's
+// rows are contiguous), the final LayerNorm - when there is one - is applied to each 128-wide pixel row while
+// it is staged into LDS (16 lanes per row, statistics by xor-shuffles), and the "other" features come from a
+// small bf16 side buffer as the last K steps.  Replaces rows_to_fc + fc_splitk and their 2 x 126 MB round trip.
+// steps_per_split is a multiple of 4, so every staged chunk of 4 K-steps is exactly one pixel row.
+__global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned short* __restrict__ rows /*[B][HW][128]*/,
+                                                                const unsigned short* __restrict__ other /*[B][other_pad]*/,
+                                                                const float* __restrict__ g, const float* __restrict__ bt,
+                                                                float eps, const unsigned short* __restrict__ Wp,
+                                                                float* __restrict__ slabs, int B, int HW, int other_pad,
+                                                                int N, int steps_per_split) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs[64 * 272];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b0 = blockIdx.x * 64;
+  const int feat_steps = HW * 4;
+  const int total_steps = feat_steps + (other_pad >> 5);
+  const int s_begin = blockIdx.y * steps_per_split;
+  const int s_end = min(s_begin + steps_per_split, total_steps);
+  float4v acc[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
+    acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool wave_active = wave * 32 < N;
+  const short8* wp = reinterpret_cast<const short8*>(Wp) + (size_t)wave * 128 + lane;
+  // this thread's slice of gamma / beta (chunk cc = tid & 15 of the 128 channels)
+  float gg[8], bb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    gg[j] = g != nullptr ? g[(tid & 15) * 8 + j] : 1.f;
+    bb[j] = g != nullptr ? bt[(tid & 15) * 8 + j] : 0.f;
+  }
+  for (int s0 = s_begin; s0 < s_end; s0 += 4) {
+    __syncthreads();
+    uint4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256, r = c >> 4, cc = c & 15;
+      v[i] = make_uint4(0, 0, 0, 0);
+      if (b0 + r < B) {
+        if (s0 < feat_steps) {
+          v[i] = *reinterpret_cast<const uint4*>(rows + ((size_t)(b0 + r) * HW + (s0 >> 2)) * 128 + cc * 8);
+        } else if ((s0 - feat_steps) * 32 + cc * 8 < other_pad) {
+          v[i] = *reinterpret_cast<const uint4*>(other + (size_t)(b0 + r) * other_pad + (s0 - feat_steps) * 32 + cc * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256, r = c >> 4, cc = c & 15;
+      short8 x = __builtin_bit_cast(short8, v[i]);
+      if (g != nullptr && s0 < feat_steps) {  // block-uniform branch: all 16 lanes of a row take it together
+        float f[8], s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f[j] = bf16_to_float((unsigned short)x[j]);
+          s += f[j];
+          ss += f[j] * f[j];
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+          s += __shfl_xor(s, off, 64);
+          ss += __shfl_xor(ss, off, 64);
+        }
+        const float mean = s * (1.0f / 128.0f);
+        const float rstd = rsqrtf(fmaxf(ss * (1.0f / 128.0f) - mean * mean, 0.f) + eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * rstd * gg[j] + bb[j];
+        x = pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+      }
+      *reinterpret_cast<short8*>(xs + r * 272 + cc * 16) = x;
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int step = s0 + ks;
+      if (step >= s_end) break;
+      const short8 w0 = wp[(size_t)step * 512];
+      const short8 w1 = wp[(size_t)step * 512 + 64];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const short8 xv = *reinterpret_cast<const short8*>(xs + (t * 16 + l15) * 272 + ks * 64 + q4 * 16);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xv, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xv, acc[t][1], 0, 0, 0);
+      }
+    }
+  }
+  if (!wave_active) return;
+  float* slab = slabs + (size_t)blockIdx.y * B * 128;
+  const int ch0 = wave * 32 + q4 * 8;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int bi = b0 + t * 16 + l15;
+    if (bi >= B) continue;
+    float* op = slab + (size_t)bi * 128 + ch0;
+    *reinterpret_cast<float4*>(op) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
+    *reinterpret_cast<float4*>(op + 4) = make_float4(acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]);
+  }
+}
+
 // h[b][n] = act(sum_s slabs[s][b][n] + bias[n]) -> bf16 [B, N]
 __global__ void fc_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ bias,
                                  unsigned short* __restrict__ out, int B, int N, int SK, int act) {
@@ -509,21 +612,30 @@ __global__ void fc_finish_kernel(const float* __restrict__ slabs, const float* _
   out[(size_t)b * N + n] = float_to_bf16(apply_act(v, act));
 }
 
-// C51 expectation: value[b] = sum_i softmax(logits[b])_i * (vmin + i*dz)
+// C51 expectation: value[b] = sum_i softmax(logits[b])_i * (vmin + i*dz).  16 lanes per sample
+// (atoms strided over the lanes, reductions by xor-shuffles inside the 16-lane group).
 __global__ void c51_expect_kernel(const float* __restrict__ logits, int stride, int atoms, float vmin, float dz,
                                   float* __restrict__ value, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const float* lp = logits + (size_t)b * stride;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gid >> 4, l = gid & 15;
+  const bool live = b < B;
+  const float* lp = logits + (size_t)(live ? b : 0) * stride;
   float m = -1e30f;
-  for (int i = 0; i < atoms; ++i) m = fmaxf(m, lp[i]);
+  for (int i = l; i < atoms; i += 16) m = fmaxf(m, lp[i]);
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   float s = 0.f, e = 0.f;
-  for (int i = 0; i < atoms; ++i) {
+  for (int i = l; i < atoms; i += 16) {
     float p = __expf(lp[i] - m);
     s += p;
     e += p * (vmin + dz * (float)i);
   }
-  value[b] = e / s;
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    e += __shfl_xor(e, off, 64);
+  }
+  if (live && l == 0) value[b] = e / s;
 }
 
 // ---------------------------------------------------------------------------
@@ -693,6 +805,21 @@ int atri_fc_splitk(const void* X, const void* Wp, float* slabs, int B, int Kp, i
   return hip_err(hipGetLastError());
 }
 
+// Fused flatten (+ final LayerNorm) + shared FC for bodies with 128 channels per pixel.  SK splits of
+// steps_per_split K-steps each (a multiple of 4); slabs is [SK][B][128] f32.
+int atri_fc_rows_splitk(const void* rows, const void* other, const float* g, const float* bt, float eps, const void* Wp,
+                        float* slabs, int B, int HW, int D, int other_pad, int N, int SK, int steps_per_split,
+                        hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (D != 128 || (other_pad & 31) != 0 || N > 128 || (N & 31) != 0) return -10;
+  if ((steps_per_split & 3) != 0 || steps_per_split <= 0) return -11;
+  if ((long long)SK * steps_per_split < (long long)HW * 4 + (other_pad >> 5)) return -12;
+  hipLaunchKernelGGL(fc_rows_splitk_kernel, dim3((B + 63) / 64, SK), dim3(256), 0, stream, (const unsigned short*)rows,
+                     (const unsigned short*)other, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
+                     steps_per_split);
+  return hip_err(hipGetLastError());
+}
+
 int atri_fc_finish(const float* slabs, const float* bias, void* out, int B, int N, int SK, int act,
                    hipStream_t stream) {
   if (B <= 0) return 0;
@@ -705,7 +832,7 @@ int atri_fc_finish(const float* slabs, const float* bias, void* out, int B, int 
 int atri_c51_expect(const float* logits, int stride, int atoms, float vmin, float dz, float* value, int B,
                     hipStream_t stream) {
   if (B <= 0) return 0;
-  hipLaunchKernelGGL(c51_expect_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, stride, atoms, vmin, dz,
+  hipLaunchKernelGGL(c51_expect_kernel, dim3((B * 16 + 255) / 256), dim3(256), 0, stream, logits, stride, atoms, vmin, dz,
                      value, B);
   return hip_err(hipGetLastError());
 }

@@ -16,8 +16,9 @@ Layer -> kernel map (default config, B leaves, HW = 120 tokens):
   4-head attention                       attention_kernel         (MFMA, softmax in registers)
   encoder layer, d_model 128 / <=128 tok attn_block_kernel + ffn_block_kernel (tf_kernels.hip; replaces the
                                          five launches above with two, activations stay in LDS / registers)
-  final LayerNorm + flatten              rows_to_fc_kernel
-  shared FC (K = 15390)                  fc_splitk_kernel + fc_finish_kernel
+  final LayerNorm + flatten + shared FC  fc_rows_splitk_kernel (128-channel bodies: LN applied while staging the
+  (K = 15390)                            rows, no flattened copy) + fc_finish_kernel; else rows_to_fc_kernel +
+                                         fc_splitk_kernel
   policy / value heads                   tile_gemm_kernel taps=1 (rows = samples)
   C51 expectation                        c51_expect_kernel
 """
@@ -203,6 +204,7 @@ class InferenceEngine:
         self.cap = 0
         self.loaded = False
         self.fc_sk = 8
+        self.fc_fused = False
         # one-workgroup-per-sample fused encoder-layer kernels (csrc/hip/tf_kernels.hip)
         self.fused_tf = bool(
             self.uses_tf and model_config.TRANSFORMER_DIM == 128 and model_config.TRANSFORMER_HEADS == 4
@@ -331,6 +333,11 @@ class InferenceEngine:
         self.value_layers = [self._linear_layer(l, bn, self.act if a else 0) for l, bn, a in _split_seq(model.value_head)]
         total_steps = self.fc_kp // 32
         self.fc_sk = max(1, min(16, total_steps // 16))
+        # 128-channel bodies feed the FC straight from their NHWC rows (flatten + final LayerNorm fused into its staging)
+        self.fc_fused = self.feat_c == 128 and self.fc_n <= 128
+        if self.fc_fused:
+            self.fc_steps_per_split = ((total_steps + self.fc_sk - 1) // self.fc_sk + 3) // 4 * 4
+            self.fc_sk = (total_steps + self.fc_steps_per_split - 1) // self.fc_steps_per_split
         self.loaded = True
 
     # ------------------------------------------------------------------ buffers
@@ -347,7 +354,8 @@ class InferenceEngine:
             widths += [3 * self.mc.TRANSFORMER_DIM, self.mc.TRANSFORMER_FC_DIM]
         maxc = max(widths)
         self.bufs = [torch.empty(rows * maxc, dtype=torch.bfloat16, device=dev) for _ in range(5)]
-        self.fc_in = torch.zeros(batch, self.fc_kp, dtype=torch.bfloat16, device=dev)
+        self.fc_in = None if self.fc_fused else torch.zeros(batch, self.fc_kp, dtype=torch.bfloat16, device=dev)
+        self.other_bf16 = torch.zeros(batch, self.other_pad, dtype=torch.bfloat16, device=dev)
         self.slabs = torch.empty(self.fc_sk, batch, 128, dtype=torch.float32, device=dev)
         dense_w = max([self.fc_n] + [l.cout for l in self.shared_rest + self.policy_layers + self.value_layers])
         self.dense = [torch.empty(batch * dense_w, dtype=torch.bfloat16, device=dev) for _ in range(3)]
@@ -369,7 +377,9 @@ class InferenceEngine:
         if conv:
             hw, h, w, rpw = self.HW, self.H, self.W, self.rows_per_wg
         else:
-            hw, h, w, rpw = 1, 1, 1, 240
+            # dense layers (rows = samples): small row blocks so a few thousand rows still cover every CU
+            rpw = min(240, max(16, 16 * ((rows + 16 * 256 - 1) // (16 * 256))))
+            hw, h, w = 1, 1, 1
         hb.call(
             "atri_tile_gemm",
             hb.ptr(src), hb.ptr(layer.w), hb.ptr(layer.bias), hb.ptr(residual), hb.ptr(layer.post_add),
@@ -441,16 +451,24 @@ class InferenceEngine:
                 self._run_gemm(tl["ff2"], bufs[h], bufs[q], rows, conv=True, residual=bufs[y])
                 x = q
             cur = x
-            g, bt, eps = self.final_ln  # type: ignore[misc]
+            ln = self.final_ln
+        else:
+            ln = None
+        if self.fc_fused:
+            hb.call("atri_other_to_fc", hb.ptr(other), hb.ptr(self.other_bf16), hb.i32(B), hb.i32(self.other_dim),
+                    hb.i32(self.other_pad), hb.i32(self.other_pad), hb.i32(0))
+            g, bt, eps = ln if ln is not None else (None, None, 0.0)
+            hb.call("atri_fc_rows_splitk", hb.ptr(bufs[cur]), hb.ptr(self.other_bf16), hb.ptr(g), hb.ptr(bt), hb.f32(eps),
+                    hb.ptr(self.fc_w), hb.ptr(self.slabs), hb.i32(B), hb.i32(self.HW), hb.i32(self.feat_c), hb.i32(self.other_pad),
+                    hb.i32(self.fc_n), hb.i32(self.fc_sk), hb.i32(self.fc_steps_per_split))
+        else:
+            g, bt, eps = ln if ln is not None else (None, None, 0.0)
             hb.call("atri_rows_to_fc", hb.ptr(bufs[cur]), hb.ptr(g), hb.ptr(bt), hb.ptr(self.fc_in), hb.i32(rows),
                     hb.i32(self.HW), hb.i32(self.feat_c), hb.i32(self.fc_kp), hb.f32(eps))
-        else:
-            hb.call("atri_rows_to_fc", hb.ptr(bufs[cur]), hb.ptr(None), hb.ptr(None), hb.ptr(self.fc_in), hb.i32(rows),
-                    hb.i32(self.HW), hb.i32(self.feat_c), hb.i32(self.fc_kp), hb.f32(0.0))
-        hb.call("atri_other_to_fc", hb.ptr(other), hb.ptr(self.fc_in), hb.i32(B), hb.i32(self.other_dim),
-                hb.i32(self.other_pad), hb.i32(self.fc_kp), hb.i32(self.HW * self.feat_c))
-        hb.call("atri_fc_splitk", hb.ptr(self.fc_in), hb.ptr(self.fc_w), hb.ptr(self.slabs), hb.i32(B), hb.i32(self.fc_kp),
-                hb.i32(self.fc_n), hb.i32(self.fc_sk))
+            hb.call("atri_other_to_fc", hb.ptr(other), hb.ptr(self.fc_in), hb.i32(B), hb.i32(self.other_dim),
+                    hb.i32(self.other_pad), hb.i32(self.fc_kp), hb.i32(self.HW * self.feat_c))
+            hb.call("atri_fc_splitk", hb.ptr(self.fc_in), hb.ptr(self.fc_w), hb.ptr(self.slabs), hb.i32(B), hb.i32(self.fc_kp),
+                    hb.i32(self.fc_n), hb.i32(self.fc_sk))
         # slabs are laid out [SK][cap][128]; the kernel indexes them with the live batch size
         hb.call("atri_fc_finish", hb.ptr(self.slabs), hb.ptr(self.fc_b), hb.ptr(self.dense[0]), hb.i32(B), hb.i32(self.fc_n),
                 hb.i32(self.fc_sk), hb.i32(self.act))
