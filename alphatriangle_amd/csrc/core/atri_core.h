@@ -99,26 +99,48 @@ ATRI_HD int sample_shape(const GeomView& g, uint64_t& rng) {
 }
 
 ATRI_HD void refill_slots(const GeomView& g, State& s) {
-  for (int i = 0; i < g.slots; ++i) s.shapes[i] = (int16_t)sample_shape(g, s.rng);
+  for (int i = 0; i < kMaxSlots; ++i)
+    if (i < g.slots) s.shapes[i] = (int16_t)sample_shape(g, s.rng);
 }
 
 ATRI_HD bool slots_all_empty(const GeomView& g, const State& s) {
-  for (int i = 0; i < g.slots; ++i)
-    if (s.shapes[i] >= 0) return false;
-  return true;
+  bool empty = true;
+  for (int i = 0; i < kMaxSlots; ++i)
+    if (i < g.slots && s.shapes[i] >= 0) empty = false;
+  return empty;
+}
+
+// State fields are always indexed with compile-time constants (select chains / guarded full-length loops):
+// on the device a State then lives in registers instead of scratch memory.
+ATRI_HD int slot_shape(const State& s, int slot) {
+  // the four int16 slots as one 64-bit word, extracted with a shift (pure ALU: a select chain over the
+  // array elements gets folded back into an indexed load by the optimiser)
+  uint64_t pk;
+  __builtin_memcpy(&pk, s.shapes, sizeof(pk));
+  return (int)(int16_t)(uint16_t)(pk >> (16 * slot));
+}
+ATRI_HD uint64_t occ_word(const State& s, int w) {
+  uint64_t v = 0;
+  for (int i = 0; i < kMaxWords; ++i) v |= s.occ[i] & (uint64_t)(-(int64_t)(w == i));
+  return v;
 }
 
 // ---------------------------------------------------------------- rules
-ATRI_HD bool action_valid(const GeomView& g, const State& s, int action) {
-  int slot = action / g.cells;
-  int pos = action - slot * g.cells;
-  int t = s.shapes[slot];
+// Validity of placing the shape of `slot` at cell `pos` (action = slot * cells + pos).
+ATRI_HD bool action_valid_sp(const GeomView& g, const State& s, int slot, int pos) {
+  int t = slot_shape(s, slot);
   if (t < 0) return false;
   if (!g.place_ok[t * g.cells + pos]) return false;
   const uint64_t* pm = g.place_mask + ((size_t)t * g.cells + pos) * g.nwords;
   uint64_t hit = 0;
-  for (int w = 0; w < g.nwords; ++w) hit |= (s.occ[w] & pm[w]);
+  for (int w = 0; w < kMaxWords; ++w)
+    if (w < g.nwords) hit |= (s.occ[w] & pm[w]);
   return hit == 0;
+}
+
+ATRI_HD bool action_valid(const GeomView& g, const State& s, int action) {
+  int slot = action / g.cells;
+  return action_valid_sp(g, s, slot, action - slot * g.cells);
 }
 
 ATRI_HD bool any_valid_action(const GeomView& g, const State& s) {
@@ -146,33 +168,35 @@ ATRI_HD void reset_state(const GeomView& g, State& s, uint64_t seed) {
 ATRI_HD void apply_action(const GeomView& g, State& s, int action, int& placed, int& cleared) {
   int slot = action / g.cells;
   int pos = action - slot * g.cells;
-  int t = s.shapes[slot];
+  int t = slot_shape(s, slot);
   const uint64_t* pm = g.place_mask + ((size_t)t * g.cells + pos) * g.nwords;
   uint64_t pl[kMaxWords];
-  for (int w = 0; w < kMaxWords; ++w) pl[w] = 0;
-  for (int w = 0; w < g.nwords; ++w) {
-    pl[w] = pm[w];
-    s.occ[w] |= pm[w];
+  for (int w = 0; w < kMaxWords; ++w) {
+    pl[w] = w < g.nwords ? pm[w] : 0;
+    s.occ[w] |= pl[w];
   }
   placed = g.tmpl_ntris[t];
   uint64_t clr[kMaxWords];
   for (int w = 0; w < kMaxWords; ++w) clr[w] = 0;
   for (int l = 0; l < g.n_lines; ++l) {
     const uint64_t* lm = g.line_mask + (size_t)l * g.nwords;
+    uint64_t lw[kMaxWords];
     bool touches = false, full = true;
-    for (int w = 0; w < g.nwords; ++w) {
-      touches |= (lm[w] & pl[w]) != 0;
-      full &= (s.occ[w] & lm[w]) == lm[w];
+    for (int w = 0; w < kMaxWords; ++w) {
+      lw[w] = w < g.nwords ? lm[w] : 0;
+      touches |= (lw[w] & pl[w]) != 0;
+      full &= (s.occ[w] & lw[w]) == lw[w];
     }
     if (touches && full)
-      for (int w = 0; w < g.nwords; ++w) clr[w] |= lm[w];
+      for (int w = 0; w < kMaxWords; ++w) clr[w] |= lw[w];
   }
   cleared = 0;
-  for (int w = 0; w < g.nwords; ++w) {
+  for (int w = 0; w < kMaxWords; ++w) {
     cleared += popc64(clr[w]);
     s.occ[w] &= ~clr[w];
   }
-  s.shapes[slot] = -1;
+  for (int i = 0; i < kMaxSlots; ++i)
+    if (i == slot) s.shapes[i] = -1;
   if (slots_all_empty(g, s)) refill_slots(g, s);
   s.step += 1;
   s.last_cleared = (int16_t)cleared;
@@ -204,9 +228,11 @@ ATRI_HD float step_state(const GeomView& g, State& s, int action) {
 ATRI_HD bool cell_bit(const uint64_t* m, int cell) { return (m[cell >> 6] >> (cell & 63)) & 1ULL; }
 
 // Grid channel 0: +1 occupied playable, 0 empty playable, -1 death cell.
+ATRI_HD bool occ_bit(const State& s, int cell) { return (occ_word(s, cell >> 6) >> (cell & 63)) & 1ULL; }
+
 ATRI_HD float grid_value(const GeomView& g, const State& s, int cell) {
   if (!cell_bit(g.playable, cell)) return -1.0f;
-  return cell_bit(s.occ, cell) ? 1.0f : 0.0f;
+  return occ_bit(s, cell) ? 1.0f : 0.0f;
 }
 
 // Column height = (row of the last occupied playable cell) + 1; holes = empty
@@ -215,13 +241,13 @@ ATRI_HD void column_stats(const GeomView& g, const State& s, int c, int& height,
   int max_r = -1;
   for (int r = 0; r < g.rows; ++r) {
     int cell = r * g.cols + c;
-    if (cell_bit(s.occ, cell) && cell_bit(g.playable, cell)) max_r = r;
+    if (occ_bit(s, cell) && cell_bit(g.playable, cell)) max_r = r;
   }
   height = max_r + 1;
   holes = 0;
   for (int r = 0; r < height; ++r) {
     int cell = r * g.cols + c;
-    if (!cell_bit(s.occ, cell) && cell_bit(g.playable, cell)) holes += 1;
+    if (!occ_bit(s, cell) && cell_bit(g.playable, cell)) holes += 1;
   }
 }
 

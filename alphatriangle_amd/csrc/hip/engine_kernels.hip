@@ -51,9 +51,29 @@ __device__ __forceinline__ NodeMeta* tree_meta(const TreeBufs& tb, int g) { retu
 __device__ __forceinline__ Edge* tree_edges(const TreeBufs& tb, int g) { return tb.edges[tb.cur[g]] + (size_t)g * tb.C * tb.A; }
 
 // ------------------------------------------------------------------ wave helpers
+// Lane-strided walk over the action space without integer division: (slot, pos) of action lane + 64k.
+struct ActionCursor {
+  int slot, pos;
+  __device__ __forceinline__ ActionCursor(const GeomView& g, int lane) : slot(0), pos(lane) { wrap(g); }
+  __device__ __forceinline__ void wrap(const GeomView& g) {
+    while (pos >= g.cells) {
+      pos -= g.cells;
+      ++slot;
+    }
+  }
+  __device__ __forceinline__ void advance(const GeomView& g) {
+    pos += 64;
+    wrap(g);
+  }
+};
+
 __device__ __forceinline__ bool wave_any_valid(const GeomView& g, const State& st, int lane) {
   bool any = false;
-  for (int a = lane; a < g.action_dim; a += 64) any |= action_valid(g, st, a);
+  ActionCursor cur(g, lane);
+  for (int a = lane; a < g.action_dim; a += 64) {
+    any |= action_valid_sp(g, st, cur.slot, cur.pos);
+    cur.advance(g);
+  }
   return __ballot(any) != 0ULL;
 }
 
@@ -85,10 +105,10 @@ __device__ void wave_features(const GeomView& g, const State& st, float* grid, f
   const int nshape = g.slots * kShapeFeat;
   for (int k = lane; k < nshape; k += 64) {
     int slot = k / kShapeFeat, f = k - slot * kShapeFeat;
-    int t = st.shapes[slot];
+    int t = slot_shape(st, slot);
     if (k < other_dim) other[k] = t >= 0 ? g.shape_feat[t * kShapeFeat + f] : 0.0f;
   }
-  if (lane < g.slots && nshape + lane < other_dim) other[nshape + lane] = st.shapes[lane] >= 0 ? 1.0f : 0.0f;
+  if (lane < g.slots && nshape + lane < other_dim) other[nshape + lane] = slot_shape(st, lane) >= 0 ? 1.0f : 0.0f;
   if (lane == 0) {
     float ex[kExplicitFeat];
     explicit_features(g, st, sum_h, max_h, holes, bump, ex);
@@ -107,14 +127,16 @@ __device__ void wave_init_edges(const GeomView& g, const State& st, Edge* ed, co
   if (g.action_dim <= kLaneActs * 64) {
     float lg[kLaneActs];
     unsigned vbits = 0;
+    ActionCursor cur(g, lane);
 #pragma unroll
     for (int k = 0; k < kLaneActs; ++k) {
       const int a = lane + 64 * k;
       lg[k] = 0.0f;
-      if (a < g.action_dim && action_valid(g, st, a)) {
+      if (a < g.action_dim && action_valid_sp(g, st, cur.slot, cur.pos)) {
         vbits |= 1u << k;
         lg[k] = logits[a];
       }
+      cur.advance(g);
     }
     float mx = -INFINITY;
 #pragma unroll
