@@ -34,6 +34,9 @@ class SystemConfig(BaseModel):
         description="Split layout: learner steps per lock-step round (one round = one self-play move on every actor rank).",
     )
     SHIP_CAPACITY: int = Field(default=1 << 15, ge=1, description="Split layout: experience records per actor per round (fixed block).")
+    OVERLAP_LEARNER: bool = Field(
+        default=True, description="Colocated GPU runs: learner steps on a second HIP stream, concurrent with the search of the move."
+    )
     USE_HIP_GRAPHS: bool = Field(default=True)
     WEIGHT_SYNC_ASYNC: bool = Field(default=True)
     DIST_BACKEND: Literal["auto", "nccl", "gloo"] = Field(default="auto", description="nccl = RCCL on ROCm.")

@@ -99,6 +99,7 @@ class GpuSelfPlayActor:
         self.total_episodes = 0
         self._ep_seen = 0
         self._graph: torch.cuda.CUDAGraph | None = None
+        self._t0 = time.perf_counter()
         self._use_graph = bool(system_config.USE_HIP_GRAPHS)
         self._grid_view = self.tree.nn_grid
         self._other_view = self.tree.nn_other
@@ -133,8 +134,13 @@ class GpuSelfPlayActor:
         self._graph = g
 
     @torch.no_grad()
-    def play_move(self) -> GpuMoveReport:
-        t0 = time.perf_counter()
+    def begin_move(self) -> None:
+        """Enqueue the whole search of one move (root evaluation + every simulation wave) without any host sync.
+
+        Returns after a few milliseconds of launches; the GPU then works for the rest of the move, which leaves
+        the host free to enqueue learner steps on another stream before :meth:`finish_move`.
+        """
+        self._t0 = time.perf_counter()
         tree = self.tree
         tree.move_stats.zero_()
         tree.prepare_roots()
@@ -155,6 +161,18 @@ class GpuSelfPlayActor:
                 for _ in range(remaining):
                     self._steady_wave()
         tree.wave(consume=True, select=False)
+
+    @torch.no_grad()
+    def finish_move(self, wait_event: "torch.cuda.Event | None" = None) -> GpuMoveReport:
+        """Commit the move (policy targets, sampling, n-step, emission into the replay), re-root, read the counters.
+
+        ``wait_event``: an event of another stream (a concurrently running learner) that must have completed
+        before the replay's sum tree is touched.
+        """
+        t0 = self._t0
+        tree = self.tree
+        if wait_event is not None:
+            torch.cuda.current_stream(self.device).wait_event(wait_event)
         self.replay.begin_commit()
         tree.commit_moves()
         tree.reroot()
@@ -187,6 +205,10 @@ class GpuSelfPlayActor:
             trainer_step=self.current_trainer_step,
             seconds=time.perf_counter() - t0,
         )
+
+    def play_move(self) -> GpuMoveReport:
+        self.begin_move()
+        return self.finish_move()
 
     # ------------------------------------------------------------------ checkpointing of the actor state
     def state_dict(self) -> dict[str, Any]:

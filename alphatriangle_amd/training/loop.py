@@ -61,6 +61,8 @@ class TrainingLoop:
             from .gpu_manager import GpuActorManager
 
             self.worker_manager: Any = GpuActorManager(components)
+            self.worker_manager.train_fn = self._train_k_steps
+            self.worker_manager.ready_fn = self.buffer.is_ready
         else:
             self.worker_manager = WorkerManager(components)
         self.loop_helpers = LoopHelpers(components, self._get_loop_state)
@@ -238,12 +240,33 @@ class TrainingLoop:
             )
         return True
 
+    def _train_k_steps(self, k: int) -> int:
+        """Up to ``k`` learner steps (GPU engine: called by the actor manager while the move's search runs)."""
+        done = 0
+        target = self.train_config.MAX_TRAINING_STEPS
+        for _ in range(k):
+            if target is not None and self.global_step >= target:
+                break
+            if not self._run_training_step():
+                break
+            done += 1
+        return done
+
+    def _checkpoint_cadence(self, steps_before: int) -> None:
+        """Trigger the periodic saves for every cadence boundary crossed since ``steps_before``."""
+        persistence = self.trieye_config.persistence
+        ckpt_freq = self.train_config.CHECKPOINT_SAVE_FREQ_STEPS
+        if ckpt_freq > 0 and self.global_step // ckpt_freq > steps_before // ckpt_freq:
+            self._trigger_save_state(is_best=False, save_buffer=False)
+        bfreq = persistence.BUFFER_SAVE_FREQ_STEPS
+        if persistence.SAVE_BUFFER and bfreq > 0 and self.global_step // bfreq > steps_before // bfreq:
+            self._trigger_save_state(is_best=False, save_buffer=True)
+
     # ------------------------------------------------------------------ main loop
     def run(self) -> None:
         target = self.train_config.MAX_TRAINING_STEPS
         logger.info("Starting TrainingLoop run... %s", f"Target steps: {target}" if target else "Running indefinitely")
         self.start_time = time.time()
-        persistence = self.trieye_config.persistence
         try:
             self.worker_manager.submit_initial_tasks()
             while not self.stop_requested.is_set():
@@ -253,23 +276,18 @@ class TrainingLoop:
                     self.request_stop()
                     break
                 trained = False
-                if self.buffer.is_ready():
+                gpu_mode = self.components.gpu_actor is not None
+                steps_before = self.global_step
+                if gpu_mode:
+                    pass  # the actor manager runs this move's learner steps (overlapped with the search)
+                elif self.buffer.is_ready():
                     trained = self._run_training_step()
                 else:
                     if not self._buffer_ready_logged and self.global_step % 100 == 0:
                         logger.debug("Waiting for buffer... Size: %d/%d", len(self.buffer), self.buffer.min_size_to_train)
-                    if self.components.gpu_actor is None:
-                        time.sleep(0.01)
-                ckpt_freq = self.train_config.CHECKPOINT_SAVE_FREQ_STEPS
-                if trained and ckpt_freq > 0 and self.global_step % ckpt_freq == 0:
-                    self._trigger_save_state(is_best=False, save_buffer=False)
-                if (
-                    trained
-                    and persistence.SAVE_BUFFER
-                    and persistence.BUFFER_SAVE_FREQ_STEPS > 0
-                    and self.global_step % persistence.BUFFER_SAVE_FREQ_STEPS == 0
-                ):
-                    self._trigger_save_state(is_best=False, save_buffer=True)
+                    time.sleep(0.01)
+                if trained:
+                    self._checkpoint_cadence(steps_before)
                 if self.stop_requested.is_set():
                     break
                 completed = self.worker_manager.get_completed_tasks(0.1 if self.buffer.is_ready() else 0.5)
@@ -286,6 +304,9 @@ class TrainingLoop:
                     else:
                         logger.error("Unexpected item from worker %d: %s", worker_id, type(item))
                     self.worker_manager.submit_task(worker_id)
+                if gpu_mode and self.global_step > steps_before:
+                    trained = True
+                    self._checkpoint_cadence(steps_before)
                 if self.stop_requested.is_set():
                     break
                 self.loop_helpers.log_progress_eta()

@@ -221,3 +221,24 @@ def test_large_preset_play_move():
     pol = replay.policy[:added]
     assert pol.shape[1] == env.ACTION_DIM
     assert torch.allclose(pol.sum(1), torch.ones(added, device=dev), atol=1e-4)
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_training_loop_on_gpu_colocated(tmp_path, overlap):
+    """The real runner on one card: GPU actor + HBM replay + learner steps (on a second stream when overlapped)."""
+    from alphatriangle_amd.stats import TrieyeConfig
+    from alphatriangle_amd.training.runner import run_training
+
+    tc = TrainConfig(DEVICE="cuda", BATCH_SIZE=64, BUFFER_CAPACITY=20_000, MIN_BUFFER_SIZE_TO_TRAIN=128, MAX_TRAINING_STEPS=12,
+                     WORKER_UPDATE_FREQ_STEPS=4, CHECKPOINT_SAVE_FREQ_STEPS=8, N_STEP_RETURNS=2, AUTO_RESUME_LATEST=False)
+    sc = SystemConfig(ENGINE="gpu", GAMES_PER_GPU=96, TRAIN_STEPS_PER_MOVE=3, OVERLAP_LEARNER=overlap, REPLAY_HBM_BUDGET_GB=4.0)
+    mcts = AlphaTriangleMCTSConfig(max_simulations=8, max_depth=4)
+    run = f"colo_{int(overlap)}"
+    tcfg = TrieyeConfig(app_name="t", run_name=run)
+    tcfg.persistence.ROOT_DATA_DIR = str(tmp_path)
+    tcfg.persistence.RUN_NAME = run
+    code = run_training("WARNING", tc, tcfg, False, model_config_override=ModelConfig(), mcts_config_override=mcts,
+                        env_config_override=EnvConfig(), system_config_override=sc)
+    assert code == 0
+    ckpt_dir = tmp_path / "t" / "runs" / run / "checkpoints"
+    assert any(p.suffix == ".pkl" for p in ckpt_dir.rglob("*")), "periodic / final checkpoint missing"
