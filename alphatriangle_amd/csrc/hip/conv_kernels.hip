@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x;
-  constexpr int stride = CIN * 2 + 16;
+  // row pitch = Cin*2 + 32 bytes = an even, non-multiple-of-4 count of 16-byte slots: the 16 lanes that one
+  // ds_read_b128 cycle serves (8 rows at slot q, 8 rows at slot q+1) then hit 16 different bank quads for every tap
+  constexpr int stride = CIN * 2 + 32;
   constexpr int KC = CIN / 32, STEPS = 9 * KC;
   const int H = a.H, W = a.W;
 
@@ -251,7 +253,7 @@ static int rowconv_impl(const void* in, const void* w, const float* bias, const 
   int l2 = 0;
   while ((1 << l2) < (Cin >> 3)) ++l2;
   a.log2_cpr = l2;
-  const int stride = Cin * 2 + 16;
+  const int stride = Cin * 2 + 32;
   const int in_bytes = kInRows * stride;
   const int out_bytes = 128 * kOutStride;
   // one output block may reuse the input tile's LDS; several blocks need the input to survive

@@ -26,7 +26,8 @@ using namespace atrihip;
 
 namespace {
 constexpr int kD = 128;          // d_model handled by these kernels
-constexpr int kStride = 272;     // LDS bytes per token row (256 + 16 pad)
+constexpr int kStride = 288;     // LDS bytes per token row: 18 slots of 16 B (even, not a multiple of 4) keeps the
+                                 // 16 lanes of a ds_read_b128 cycle on 16 different bank quads
 constexpr int kRows = 128;       // token rows per tile (8 M-tiles of 16)
 constexpr int kTileBytes = kRows * kStride;
 
@@ -194,41 +195,33 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   __syncthreads();
 
   short8 Qf[8], Kf[8], VTf[4][2];
-  {  // ---- K_w
-    float4v acc[8][2];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
-    load_wfrags(wb, wq + (size_t)8 * 512);  // V weights fly during the K GEMM
-    gemm_k128<false>(acc, wa, xn, l15, q4);
+  {  // ---- K_w (bias preloaded into the accumulators: the MFMA adds it for free)
     float bias[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[kD + wave * 32 + q4 * 8 + i];
+    float4v acc[8][2];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[t][0][j] += bias[j];
-        acc[t][1][j] += bias[4 + j];
-      }
-      Kf[t] = pack8(acc[t][0], acc[t][1]);
+      acc[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
+      acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
     }
+    load_wfrags(wb, wq + (size_t)8 * 512);  // V weights fly during the K GEMM
+    gemm_k128<false>(acc, wa, xn, l15, q4);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) Kf[t] = pack8(acc[t][0], acc[t][1]);
   }
   __builtin_amdgcn_sched_barrier(0);
   {  // ---- V_w with swapped operands: acc[t][n][j] = V[token t*16 + 4q4 + j][dim perm(l15, n)]
-    float4v acc[8][2];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
-    load_wfrags(wa, wq);  // Q weights fly during the V GEMM
-    gemm_k128<true>(acc, wb, xn, l15, q4);
     const int chp = (l15 >> 2) * 8 + (l15 & 3);
     const float bv0 = a.bqkv[2 * kD + wave * 32 + chp], bv1 = a.bqkv[2 * kD + wave * 32 + chp + 4];
+    float4v acc[8][2];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[t][0][j] += bv0;
-        acc[t][1][j] += bv1;
-      }
+    for (int t = 0; t < 8; ++t) {
+      acc[t][0] = (float4v){bv0, bv0, bv0, bv0};
+      acc[t][1] = (float4v){bv1, bv1, bv1, bv1};
+    }
+    load_wfrags(wa, wq);  // Q weights fly during the V GEMM
+    gemm_k128<true>(acc, wb, xn, l15, q4);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       VTf[kb][0] = pack8(acc[2 * kb][0], acc[2 * kb + 1][0]);
@@ -238,27 +231,24 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
 
   __builtin_amdgcn_sched_barrier(0);
   {  // ---- Q_w : lane ends with dims 8q4..8q4+7 of token (t*16 + l15)
-    float4v acc[8][2];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
-    gemm_k128<false>(acc, wa, xn, l15, q4);
     float bias[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[wave * 32 + q4 * 8 + i];
+    float4v acc[8][2];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[t][0][j] += bias[j];
-        acc[t][1][j] += bias[4 + j];
-      }
-      Qf[t] = pack8(acc[t][0], acc[t][1]);
+      acc[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
+      acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
     }
+    gemm_k128<false>(acc, wa, xn, l15, q4);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) Qf[t] = pack8(acc[t][0], acc[t][1]);
   }
   load_wfrags(wb, reinterpret_cast<const short8*>(a.wo) + (size_t)wave * 128 + lane);  // out-proj weights fly during attention
   // ---- attention of head `wave`, one 16-query tile at a time
   const int n_qt = (HW + 15) >> 4;
   const int kt_full = HW >> 4;  // key tiles below this index hold no padding
+  const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
 #pragma unroll
   for (int qt = 0; qt < 8; ++qt) {
     if (qt >= n_qt) break;
@@ -278,25 +268,22 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float p = __builtin_amdgcn_exp2f(st[kt][j] - m);  // scores arrive in log2 units
-        st[kt][j] = p;
-        sum += p;
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) st[kt][j] = __builtin_amdgcn_exp2f(st[kt][j] - m);  // scores arrive in log2 units
+    // O^T = V^T P^T, and the softmax denominators come out of the same MFMA pass: a ones fragment as a third
+    // "V^T" tile makes every row of that tile the column sums of P^T (the matrix core is idle enough to take
+    // the 32 adds + 2 shuffles per query tile off the VALU; the sums are over the bf16 P that P.V really uses)
+    float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f}, os = (float4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const short8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
       o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][0], pf, o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][1], pf, o1, 0, 0, 0);
+      os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
     }
+    const float inv = 1.0f / os[0];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       o0[j] *= inv;
@@ -368,32 +355,43 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
   layernorm_rows(yn, HW, a.ln_g, a.ln_b, a.ln_eps, tid);
   __syncthreads();
 
-  float4v acc_o[8][2];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) acc_o[t][0] = acc_o[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
   const int ch0 = wave * 32 + q4 * 8;
+  float4v acc_o[8][2];
+  {  // output bias preloaded into the accumulators
+    float b2v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b2v[i] = a.b2[ch0 + i];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      acc_o[t][0] = (float4v){b2v[0], b2v[1], b2v[2], b2v[3]};
+      acc_o[t][1] = (float4v){b2v[4], b2v[5], b2v[6], b2v[7]};
+    }
+  }
   constexpr int halves = HALVES;
   ResFrags res;
 #pragma unroll
   for (int h = 0; h < halves; ++h) {
     {
-      float4v acc_h[8][2];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc_h[t][0] = acc_h[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
-      load_wfrags(wb, w2p + (size_t)h * 4 * 512);  // this half's W2 steps fly during the first GEMM
-      gemm_k128<false>(acc_h, wa, yn, l15, q4);
-      if (h + 1 < halves) load_wfrags(wa, w1p + (size_t)(h + 1) * 4 * 512);  // next W1 block flies during the second GEMM
       float bias[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) bias[i] = a.b1[h * 128 + ch0 + i];
+      float4v acc_h[8][2];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        acc_h[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
+        acc_h[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
+      }
+      load_wfrags(wb, w2p + (size_t)h * 4 * 512);  // this half's W2 steps fly during the first GEMM
+      gemm_k128<false>(acc_h, wa, yn, l15, q4);
+      if (h + 1 < halves) load_wfrags(wa, w1p + (size_t)(h + 1) * 4 * 512);  // next W1 block flies during the second GEMM
       if (h > 0) __syncthreads();  // the previous half's second GEMM has finished reading the hidden tile
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[j] = acc_h[t][0][j] + bias[j];
-          v[4 + j] = acc_h[t][1][j] + bias[4 + j];
+          v[j] = acc_h[t][0][j];
+          v[4 + j] = acc_h[t][1][j];
         }
         if (a.act == kActReLU) {
 #pragma unroll
@@ -411,9 +409,6 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
     gemm_k128<false>(acc_o, wb, hh, l15, q4);
   }
 
-  float bias[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) bias[i] = a.b2[ch0 + i];
   unsigned short* og = a.out + (size_t)b * HW * kD;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -423,8 +418,8 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
     float o[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      o[j] = acc_o[t][0][j] + bias[j] + bf16_to_float((unsigned short)res.r[t][j]);
-      o[4 + j] = acc_o[t][1][j] + bias[4 + j] + bf16_to_float((unsigned short)res.r[t][4 + j]);
+      o[j] = acc_o[t][0][j] + bf16_to_float((unsigned short)res.r[t][j]);
+      o[4 + j] = acc_o[t][1][j] + bf16_to_float((unsigned short)res.r[t][4 + j]);
     }
     *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
   }
