@@ -120,6 +120,31 @@ def build_hip(force: bool = False, verbose: bool = True) -> Path:
     return HIP_SO
 
 
+SANITIZERS = {"address": "address,undefined", "thread": "thread"}
+
+
+def build_selftest(kind: str = "address", verbose: bool = True) -> Path:
+    """Build the stand-alone host-runtime exerciser with ``-fsanitize=<kind>`` (address+undefined or thread).
+
+    The sanitized process contains only the C++ runtime (engine, search, sum tree, metric ring), so no
+    Python allocator noise and no preloading is needed; ``tests/test_host_sanitizers.py`` runs the binaries.
+    """
+    if kind not in SANITIZERS:
+        raise ValueError(f"unknown sanitizer '{kind}' (choose from {sorted(SANITIZERS)})")
+    out_dir = PKG_DIR / "build" / "selftest"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    out = out_dir / f"host_selftest_{kind}"
+    src = CSRC / "selftest" / "host_selftest.cpp"
+    cmd = [
+        os.environ.get("CXX", "g++"), "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-omit-frame-pointer",
+        f"-fsanitize={SANITIZERS[kind]}", str(src), "-o", str(out), "-pthread",
+    ]
+    if verbose:
+        print("[build_native] selftest:", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_all(force: bool = False, verbose: bool = True) -> None:
     build_host(force, verbose)
     build_hip(force, verbose)
@@ -128,7 +153,11 @@ def build_all(force: bool = False, verbose: bool = True) -> None:
 if __name__ == "__main__":
     args = set(sys.argv[1:])
     force = "--force" in args
-    if "--host" in args:
+    if "--selftest" in args:
+        kinds = [a for a in args if a in SANITIZERS] or list(SANITIZERS)
+        for k in kinds:
+            print(build_selftest(k))
+    elif "--host" in args:
         build_host(force)
     elif "--hip" in args:
         build_hip(force)

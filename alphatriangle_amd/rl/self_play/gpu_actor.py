@@ -100,6 +100,7 @@ class GpuSelfPlayActor:
         self._ep_seen = 0
         self._graph: torch.cuda.CUDAGraph | None = None
         self._t0 = time.perf_counter()
+        self.profile_ranges = bool(train_config.PROFILE_WORKERS)  # --profile: roctx ranges around the move phases
         self._use_graph = bool(system_config.USE_HIP_GRAPHS)
         self._grid_view = self.tree.nn_grid
         self._other_view = self.tree.nn_other
@@ -143,9 +144,13 @@ class GpuSelfPlayActor:
         self._t0 = time.perf_counter()
         tree = self.tree
         tree.move_stats.zero_()
+        rng = self._range
+        rng("selfplay/root_eval")
         tree.prepare_roots()
         self._forward()
         tree.init_roots()
+        rng(None)
+        rng("selfplay/waves")
         waves = self.waves_per_move
         tree.wave(consume=False, select=True)
         self._forward()
@@ -161,6 +166,16 @@ class GpuSelfPlayActor:
                 for _ in range(remaining):
                     self._steady_wave()
         tree.wave(consume=True, select=False)
+        rng(None)
+
+    def _range(self, name: str | None) -> None:
+        """roctx range markers (visible in rocprofv3 --marker-trace) when profiling is switched on."""
+        if not self.profile_ranges:
+            return
+        if name is None:
+            torch.cuda.nvtx.range_pop()
+        else:
+            torch.cuda.nvtx.range_push(name)
 
     @torch.no_grad()
     def finish_move(self, wait_event: "torch.cuda.Event | None" = None) -> GpuMoveReport:
@@ -173,10 +188,12 @@ class GpuSelfPlayActor:
         tree = self.tree
         if wait_event is not None:
             torch.cuda.current_stream(self.device).wait_event(wait_event)
+        self._range("selfplay/commit")
         self.replay.begin_commit()
         tree.commit_moves()
         tree.reroot()
         added = self.replay.end_commit()
+        self._range(None)
         stats = tree.move_stats.cpu().numpy()
         ep_total = int(tree.ep_count.item())
         new_eps = ep_total - self._ep_seen

@@ -166,6 +166,12 @@ class TrainingLoop:
             ctx["trainer_step"] = report.trainer_step
             self._send_event_async("episode_end", 1.0, ctx)
         self._send_event_async("mcts_step", float(report.simulations), {"moves": report.moves})
+        # per-move aggregates over all games (the CPU worker sends these per game step)
+        self._send_event_async("step_reward", float(report.mean_step_reward), {"moves": report.moves})
+        self._send_event_async("triangles_cleared_step", float(report.triangles_cleared), {"moves": report.moves})
+        if report.episode_contexts:
+            scores = [c["score"] for c in report.episode_contexts]
+            self._send_event_async("current_score", float(sum(scores) / len(scores)), {"episodes": len(scores)})
         if report.episodes_finished:
             self._send_event_async("Progress/Episodes_Played", self.episodes_played)
         self._send_event_async("Progress/Total_Simulations", self.total_simulations_run)
