@@ -28,6 +28,11 @@ struct RowConvArgs {
   const float* post_add;           // [HW, Cout] f32 or nullptr (added after the activation)
   unsigned short* out;             // [B, HW, Cout] bf16
   int B, H, W, HW, Cin, Cout, act, n_blocks, log2_cpr, out_off, ymagic;
+  // FIRST instantiation only: the network's first layer (1 input channel, 3x3) is evaluated while staging
+  const float* grid;     // [B, HW] f32 board planes
+  const float* w_first;  // [9][Cin] f32 (BatchNorm folded)
+  const float* b_first;  // [Cin]
+  int first_act, aux_off;
 };
 
 namespace {
@@ -43,7 +48,9 @@ __device__ __noinline__ float4v act8_slow_rc(float4v v, int act) {
 
 // DBG != 0 instantiations are roofline probes (bench/conv_probe.py), bit mask: 1 no LDS fragment reads,
 // 2 no weight-fragment loads, 4 no main loop, 16 no input staging loads, 32 no write-back phase.
-template <int CIN, int DBG>
+// FIRST: the input tile is not read from memory but computed from the raw board (first conv layer, Cin_first = 1),
+// which removes a separate memory-bound kernel and the round trip of its output.
+template <int CIN, int DBG, bool FIRST = false>
 __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,7 +63,46 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
   const int H = a.H, W = a.W;
 
   // ---- stage the sample with its zero halo; eight global loads in flight per thread ----
-  {
+  if (FIRST) {
+    // board plane, first-layer weights and bias go to a side area of LDS, then every thread evaluates the
+    // 3x3 single-channel conv for its (pixel, 8-channel) chunks straight into the halo tile
+    float* aux = reinterpret_cast<float*>(smem + a.aux_off);
+    float* gplane = aux;                   // [HW]
+    float* wl = aux + 128;                 // [9][CIN]
+    float* bl = wl + 9 * CIN;              // [CIN]
+    for (int i = tid; i < a.HW; i += 256) gplane[i] = a.grid[(size_t)b * a.HW + i];
+    for (int i = tid; i < 9 * CIN; i += 256) wl[i] = a.w_first[i];
+    for (int i = tid; i < CIN; i += 256) bl[i] = a.b_first[i];
+    __syncthreads();
+    constexpr int CPR = CIN / 8;
+    for (int c = tid; c < kInRows * CPR; c += 256) {
+      const int r = c / CPR, cc = c - r * CPR;
+      const int rr = r - 17, y = rr >> 4, x = rr & 15;
+      short8 o = (short8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (rr >= 0 && y < H && x < W) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bl[cc * 8 + j];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+          const float gv = gplane[yy * W + xx];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += gv * wl[tap * CIN + cc * 8 + j];
+        }
+        if (a.first_act == kActReLU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], a.first_act);
+        }
+        o = pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+      }
+      *reinterpret_cast<short8*>(smem + r * stride + cc * 16) = o;
+    }
+  } else {
     const int cmask = (1 << a.log2_cpr) - 1;
     const int total = kInRows << a.log2_cpr;
     const unsigned short* src = a.in + (size_t)b * a.HW * a.Cin;
@@ -211,21 +257,22 @@ int atri_rowconv_supported(int H, int W, int Cin, int Cout) {
 }  // extern "C"
 
 namespace {
+template <int CIN, int DBG, bool FIRST>
+int launch_rowconv_inst(const RowConvArgs& a, int lds, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)rowconv_kernel<CIN, DBG, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((rowconv_kernel<CIN, DBG, FIRST>), dim3(a.B), dim3(256), lds, stream, a);
+  return hip_err(hipGetLastError());
+}
+
 template <int DBG>
 int launch_rowconv(const RowConvArgs& a, int lds, hipStream_t stream) {
-  static bool attr[3] = {false, false, false};
-  const int ci = a.Cin == 32 ? 0 : a.Cin == 64 ? 1 : 2;
-  const void* fn = ci == 0   ? (const void*)rowconv_kernel<32, DBG>
-                   : ci == 1 ? (const void*)rowconv_kernel<64, DBG>
-                             : (const void*)rowconv_kernel<128, DBG>;
-  if (!attr[ci]) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr[ci] = true;
-  }
-  if (ci == 0) hipLaunchKernelGGL((rowconv_kernel<32, DBG>), dim3(a.B), dim3(256), lds, stream, a);
-  else if (ci == 1) hipLaunchKernelGGL((rowconv_kernel<64, DBG>), dim3(a.B), dim3(256), lds, stream, a);
-  else hipLaunchKernelGGL((rowconv_kernel<128, DBG>), dim3(a.B), dim3(256), lds, stream, a);
-  return hip_err(hipGetLastError());
+  if (a.Cin == 32) return launch_rowconv_inst<32, DBG, false>(a, lds, stream);
+  if (a.Cin == 64) return launch_rowconv_inst<64, DBG, false>(a, lds, stream);
+  return launch_rowconv_inst<128, DBG, false>(a, lds, stream);
 }
 }  // namespace
 
@@ -235,7 +282,7 @@ static int rowconv_impl(const void* in, const void* w, const float* bias, const 
   if (B <= 0) return 0;
   if (!atri_rowconv_supported(H, W, Cin, Cout)) return -10;
   if (n_blocks * 128 < Cout) return -11;
-  RowConvArgs a;
+  RowConvArgs a{};
   a.in = (const unsigned short*)in;
   a.w = (const unsigned short*)w;
   a.bias = bias;
@@ -279,6 +326,45 @@ extern "C" {
 int atri_rowconv(const void* in, const void* w, const float* bias, const void* residual, const float* post_add, void* out,
                  int B, int H, int W, int Cin, int Cout, int act, int n_blocks, hipStream_t stream) {
   return rowconv_impl(in, w, bias, residual, post_add, out, B, H, W, Cin, Cout, act, n_blocks, 0, stream);
+}
+
+// First conv layer (1 input channel) fused into the staging of the second one: grid f32 [B, HW] -> out [B, HW, Cout].
+// w_first [9][Cin] / b_first [Cin] are the first layer's folded weights, (w, bias) the second layer's.
+int atri_rowconv_first(const float* grid, const float* w_first, const float* b_first, int first_act, const void* w,
+                       const float* bias, void* out, int B, int H, int W, int Cin, int Cout, int act, int n_blocks,
+                       hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (!atri_rowconv_supported(H, W, Cin, Cout) || H * W > 128) return -10;
+  if (n_blocks * 128 < Cout) return -11;
+  RowConvArgs a{};
+  a.w = (const unsigned short*)w;
+  a.bias = bias;
+  a.out = (unsigned short*)out;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.HW = H * W;
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.act = act;
+  a.n_blocks = n_blocks;
+  a.grid = grid;
+  a.w_first = w_first;
+  a.b_first = b_first;
+  a.first_act = first_act;
+  const int stride = Cin * 2 + 32;
+  const int in_bytes = kInRows * stride;
+  const int out_bytes = 128 * kOutStride;
+  a.out_off = (n_blocks > 1) ? in_bytes : 0;
+  int lds = (n_blocks > 1) ? in_bytes + out_bytes : (in_bytes > out_bytes ? in_bytes : out_bytes);
+  a.aux_off = (lds + 15) & ~15;              // board plane + first-layer weights live behind the tiles
+  lds = a.aux_off + (128 + 10 * Cin) * 4;
+  a.ymagic = 65536 / W + 1;
+  for (int p = 0; p < a.HW; ++p)
+    if (((p * a.ymagic) >> 16) != p / W) return -12;
+  if (Cin == 32) return launch_rowconv_inst<32, 0, true>(a, lds, stream);
+  if (Cin == 64) return launch_rowconv_inst<64, 0, true>(a, lds, stream);
+  return launch_rowconv_inst<128, 0, true>(a, lds, stream);
 }
 
 // Roofline probe: the same launch with ingredients removed (see the kernel's DBG parameter).

@@ -8,7 +8,8 @@ reference is the eval-mode PyTorch module (models/model.py); the network itself
 is the reference's (alphatriangle/nn/model.py:109-297).
 
 Layer -> kernel map (default config, B leaves, HW = 120 tokens):
-  conv stem layer 0 (Cin = 1)            conv_first_kernel        (VALU, memory bound)
+  conv stem layer 0 (Cin = 1)            evaluated inside the staging of layer 1's rowconv_kernel (boards up to 8x15),
+                                         else conv_first_kernel (VALU, memory bound)
   conv stem 1.., residual convs          rowconv_kernel (boards up to 8x15: halo tile in LDS, one sample per
                                          workgroup, coalesced write-back) else tile_gemm_kernel taps=9
   1x1 projections, QKV, out-proj, FFN    tile_gemm_kernel taps=1  (+LayerNorm prologue,
@@ -409,10 +410,24 @@ class InferenceEngine:
             raise ValueError("feature tensor shapes do not match the engine configuration")
         rows = B * self.HW
         bufs = self.bufs
-        hb.call("atri_conv_first", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.ptr(bufs[0]),
-                hb.i32(rows), hb.i32(self.HW), hb.i32(self.H), hb.i32(self.W), hb.i32(self.c0), hb.i32(self.act))
         cur = 0  # index of the buffer holding the current activation
-        for kind, layer in self.body_layers:
+        body = self.body_layers
+        fuse_first = (
+            self.use_rowconv and body and body[0][0] == "plain" and body[0][1].post_add is None and body[0][1].taps == 9
+            and self.H <= 8 and self.W <= 15 and self.c0 in (32, 64, 128) and _pow2(body[0][1].cout)
+        )
+        if fuse_first:
+            # first layer (1 input channel) evaluated inside the staging of the second one: no separate kernel
+            l1 = body[0][1]
+            hb.call("atri_rowconv_first", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.i32(self.act), hb.ptr(l1.w),
+                    hb.ptr(l1.bias), hb.ptr(bufs[1]), hb.i32(B), hb.i32(self.H), hb.i32(self.W), hb.i32(l1.cin), hb.i32(l1.cout),
+                    hb.i32(l1.act), hb.i32(l1.n_blocks))
+            cur = 1
+            body = body[1:]
+        else:
+            hb.call("atri_conv_first", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.ptr(bufs[0]),
+                    hb.i32(rows), hb.i32(self.HW), hb.i32(self.H), hb.i32(self.W), hb.i32(self.c0), hb.i32(self.act))
+        for kind, layer in body:
             if kind in ("plain", "res_a"):
                 dst = (cur + 1) % 3
                 self._run_gemm(layer, bufs[cur], bufs[dst], rows, conv=True)
