@@ -109,13 +109,16 @@ __device__ __forceinline__ void load_wfrags(WFrags& w, const short8* __restrict_
 
 // The residual fragment a lane needs in the epilogue (8 channels of token t*16 + l15, t = 0..7), requested
 // before the last GEMM so its HBM/L2 latency hides behind the MFMAs.
-struct ResFrags {
-  short8 r[8];
+template <int MT = 8>
+struct ResFragsT {
+  short8 r[MT];
 };
-__device__ __forceinline__ void load_residual(ResFrags& rf, const unsigned short* __restrict__ rowbase, int HW, int l15) {
+using ResFrags = ResFragsT<8>;
+template <int MT>
+__device__ __forceinline__ void load_residual(ResFragsT<MT>& rf, const unsigned short* __restrict__ rowbase, int HW, int l15) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
+  for (int t = 0; t < MT; ++t) {
     const int r = t * 16 + l15;
     rf.r[t] = (short8){0, 0, 0, 0, 0, 0, 0, 0};
     if (r < HW) rf.r[t] = *reinterpret_cast<const short8*>(rowbase + (size_t)r * kD);
@@ -128,26 +131,27 @@ __device__ __forceinline__ void load_residual(ResFrags& rf, const unsigned short
 // SWAP = true : the tile is the A operand (lane ends with 4 consecutive tokens of one output channel).
 // The LDS fragments are software pipelined in half steps (4 row tiles) between sched_barrier fences, which
 // keep the compiler from sinking each load down to the MFMA that consumes it.
-template <bool SWAP>
-__device__ __forceinline__ void gemm_k128(float4v (&acc)[8][2], const WFrags& w, const unsigned char* tile, int l15, int q4) {
-  short8 av[2][4];
+template <bool SWAP, int MT = 8>
+__device__ __forceinline__ void gemm_k128(float4v (&acc)[MT][2], const WFrags& w, const unsigned char* tile, int l15, int q4) {
+  constexpr int HT = MT / 2;  // row tiles per pipelined half step
+  short8 av[2][HT];
   const unsigned char* lane_base = tile + l15 * kStride + q4 * 16;
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) av[0][t] = *reinterpret_cast<const short8*>(lane_base + t * 16 * kStride);
+  for (int t = 0; t < HT; ++t) av[0][t] = *reinterpret_cast<const short8*>(lane_base + t * 16 * kStride);
 #pragma unroll
   for (int hs = 0; hs < 8; ++hs) {
     const int kc = hs >> 1, half = hs & 1, cur = hs & 1, nxt = cur ^ 1;
     __builtin_amdgcn_sched_barrier(0);
     if (hs + 1 < 8) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        av[nxt][t] = *reinterpret_cast<const short8*>(lane_base + (((hs + 1) & 1) * 4 + t) * 16 * kStride + ((hs + 1) >> 1) * 64);
+      for (int t = 0; t < HT; ++t)
+        av[nxt][t] = *reinterpret_cast<const short8*>(lane_base + (((hs + 1) & 1) * HT + t) * 16 * kStride + ((hs + 1) >> 1) * 64);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int tt = half * 4 + t;
+    for (int t = 0; t < HT; ++t) {
+      const int tt = half * HT + t;
       if (SWAP) {
         acc[tt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[cur][t], w.f[kc][0], acc[tt][0], 0, 0, 0);
         acc[tt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[cur][t], w.f[kc][1], acc[tt][1], 0, 0, 0);
@@ -322,71 +326,92 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
 }
 
 struct FfnBlockArgs {
-  const unsigned short* y;   // [B, HW, 128]
-  unsigned short* out;       // [B, HW, 128]
+  const unsigned short* y;   // [rows, 128]
+  unsigned short* out;       // [rows, 128]
   const unsigned short* w1;  // packed [F/128 blocks][4 steps]...
   const float* b1;           // [F]
   const unsigned short* w2;  // packed [1][F/32 steps]...
   const float* b2;           // [128]
   const float* ln_g;
   const float* ln_b;
-  int B, HW, F, act;
+  int rows, F, act;
   float ln_eps;
 };
 
+// The FFN block is token-wise, so it is tiled over the flat [batch * tokens, 128] row space in blocks of 64 rows
+// (4 M-tiles) regardless of sample boundaries: 37 KB of LDS and < 168 VGPRs per workgroup give three resident
+// workgroups (12 waves) per CU, which is what hides the serial stage -> LN -> GEMM -> act -> GEMM -> store chain of
+// each of them.  Works for any token count.
 // HALVES = F / 128 (compile time so that every prefetch below has a statically known live range).
+constexpr int kFfnTiles = 4;
+constexpr int kFfnRows = kFfnTiles * 16;
+constexpr int kFfnTileBytes = kFfnRows * kStride;
+
 template <int HALVES>
-__global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
+__global__ __launch_bounds__(256, 3) void ffn_block_kernel(FfnBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* yn = smem;
-  unsigned char* hh = smem + kTileBytes;
+  unsigned char* hh = smem + kFfnTileBytes;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
-  const int b = blockIdx.x;
-  const int HW = a.HW;
-  const unsigned short* yg = a.y + (size_t)b * HW * kD;
+  const int row0 = blockIdx.x * kFfnRows;
+  const int nrows = min(kFfnRows, a.rows - row0);
+  const unsigned short* yg = a.y + (size_t)row0 * kD;
 
   const short8* w1p = reinterpret_cast<const short8*>(a.w1) + (size_t)wave * 128 + lane;
   const short8* w2p = reinterpret_cast<const short8*>(a.w2) + (size_t)wave * 128 + lane;
   WFrags wa, wb;
   load_wfrags(wa, w1p);  // first W1 block: in flight during staging and LayerNorm
-  stage_tile(yg, yn, HW, tid);
+  {  // stage 64 rows x 16 chunks (rows beyond the end zeroed), loads issued before writes
+    uint4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256;
+      v[i] = make_uint4(0, 0, 0, 0);
+      if (c < nrows * 16) v[i] = *reinterpret_cast<const uint4*>(yg + (size_t)c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256;
+      *reinterpret_cast<uint4*>(yn + (c >> 4) * kStride + (c & 15) * 16) = v[i];
+    }
+  }
   __syncthreads();
-  layernorm_rows(yn, HW, a.ln_g, a.ln_b, a.ln_eps, tid);
+  layernorm_rows(yn, nrows, a.ln_g, a.ln_b, a.ln_eps, tid);
   __syncthreads();
 
   const int ch0 = wave * 32 + q4 * 8;
-  float4v acc_o[8][2];
+  float4v acc_o[kFfnTiles][2];
   {  // output bias preloaded into the accumulators
     float b2v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) b2v[i] = a.b2[ch0 + i];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < kFfnTiles; ++t) {
       acc_o[t][0] = (float4v){b2v[0], b2v[1], b2v[2], b2v[3]};
       acc_o[t][1] = (float4v){b2v[4], b2v[5], b2v[6], b2v[7]};
     }
   }
   constexpr int halves = HALVES;
-  ResFrags res;
+  ResFragsT<kFfnTiles> res;
 #pragma unroll
   for (int h = 0; h < halves; ++h) {
     {
       float bias[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) bias[i] = a.b1[h * 128 + ch0 + i];
-      float4v acc_h[8][2];
+      float4v acc_h[kFfnTiles][2];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int t = 0; t < kFfnTiles; ++t) {
         acc_h[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
         acc_h[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
       }
       load_wfrags(wb, w2p + (size_t)h * 4 * 512);  // this half's W2 steps fly during the first GEMM
-      gemm_k128<false>(acc_h, wa, yn, l15, q4);
+      gemm_k128<false, kFfnTiles>(acc_h, wa, yn, l15, q4);
       if (h + 1 < halves) load_wfrags(wa, w1p + (size_t)(h + 1) * 4 * 512);  // next W1 block flies during the second GEMM
       if (h > 0) __syncthreads();  // the previous half's second GEMM has finished reading the hidden tile
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int t = 0; t < kFfnTiles; ++t) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -405,16 +430,16 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(FfnBlockArgs a) {
       }
     }
     __syncthreads();
-    if (h + 1 == halves) load_residual(res, yg + ch0, HW, l15);
-    gemm_k128<false>(acc_o, wb, hh, l15, q4);
+    if (h + 1 == halves) load_residual(res, yg + ch0, nrows, l15);
+    gemm_k128<false, kFfnTiles>(acc_o, wb, hh, l15, q4);
   }
 
-  unsigned short* og = a.out + (size_t)b * HW * kD;
+  unsigned short* og = a.out + (size_t)row0 * kD;
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
+  for (int t = 0; t < kFfnTiles; ++t) {
     int r = t * 16 + l15;
     asm volatile("" : "+v"(r));
-    if (r >= HW) continue;
+    if (r >= nrows) continue;
     float o[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -430,10 +455,10 @@ template <int HALVES>
 int launch_ffn(const FfnBlockArgs& a, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)ffn_block_kernel<HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
+    (void)hipFuncSetAttribute((const void*)ffn_block_kernel<HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFfnTileBytes);
     attr = true;
   }
-  hipLaunchKernelGGL(ffn_block_kernel<HALVES>, dim3(a.B), dim3(256), 2 * kTileBytes, stream, a);
+  hipLaunchKernelGGL(ffn_block_kernel<HALVES>, dim3((a.rows + kFfnRows - 1) / kFfnRows), dim3(256), 2 * kFfnTileBytes, stream, a);
   return (int)hipGetLastError();
 }
 }  // namespace
@@ -460,10 +485,10 @@ int atri_ffn_block(const void* y, void* out, const void* w1, const float* b1, co
                    const float* ln_g, const float* ln_b, int B, int HW, int D, int F, int act, float ln_eps,
                    hipStream_t stream) {
   if (B <= 0) return 0;
-  if (D != kD || (F & 127) != 0 || F < 128 || HW > kRows || HW < 1) return -10;
+  if (D != kD || (F & 127) != 0 || F < 128 || HW < 1) return -10;
   if (act != kActReLU && act != kActGELU) return -11;
   FfnBlockArgs a{(const unsigned short*)y, (unsigned short*)out, (const unsigned short*)w1, b1,
-                 (const unsigned short*)w2, b2, ln_g, ln_b, B, HW, F, act, ln_eps};
+                 (const unsigned short*)w2, b2, ln_g, ln_b, B * HW, F, act, ln_eps};
   switch (F >> 7) {
     case 1: return launch_ffn<1>(a, stream);
     case 2: return launch_ffn<2>(a, stream);

@@ -211,6 +211,11 @@ class InferenceEngine:
             self.uses_tf and model_config.TRANSFORMER_DIM == 128 and model_config.TRANSFORMER_HEADS == 4
             and self.HW <= 128 and model_config.TRANSFORMER_FC_DIM % 128 == 0
         )
+        # the FFN half of an encoder layer is token-wise: its fused kernel is tiled over flat rows and works for any board
+        self.fused_ffn = bool(
+            self.uses_tf and model_config.TRANSFORMER_DIM == 128 and model_config.TRANSFORMER_FC_DIM % 128 == 0
+            and model_config.TRANSFORMER_FC_DIM <= 512
+        )
         self.use_rowconv = True  # tests flip this to cover the generic tile kernel on small boards
         self._store: list[torch.Tensor] = []
         self._store_cursor = 0
@@ -462,8 +467,14 @@ class InferenceEngine:
                 self._run_gemm(tl["qkv"], bufs[x], bufs[q], rows, conv=True)
                 hb.call("atri_attention", hb.ptr(bufs[q]), hb.ptr(bufs[t]), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads))
                 self._run_gemm(tl["out"], bufs[t], bufs[y], rows, conv=True, residual=bufs[x])
-                self._run_gemm(tl["ff1"], bufs[y], bufs[h], rows, conv=True)
-                self._run_gemm(tl["ff2"], bufs[h], bufs[q], rows, conv=True, residual=bufs[y])
+                if self.fused_ffn:
+                    ff1, ff2 = tl["ff1"], tl["ff2"]
+                    hb.call("atri_ffn_block", hb.ptr(bufs[y]), hb.ptr(bufs[q]), hb.ptr(ff1.w), hb.ptr(ff1.bias),
+                            hb.ptr(ff2.w), hb.ptr(ff2.bias), hb.ptr(ff1.ln_g), hb.ptr(ff1.ln_b), hb.i32(B), hb.i32(self.HW),
+                            hb.i32(D), hb.i32(ff1.cout), hb.i32(self.act), hb.f32(ff1.ln_eps))
+                else:
+                    self._run_gemm(tl["ff1"], bufs[y], bufs[h], rows, conv=True)
+                    self._run_gemm(tl["ff2"], bufs[h], bufs[q], rows, conv=True, residual=bufs[y])
                 x = q
             cur = x
             ln = self.final_ln
