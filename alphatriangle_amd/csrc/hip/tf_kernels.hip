@@ -463,6 +463,260 @@ int launch_ffn(const FfnBlockArgs& a, hipStream_t stream) {
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// Encoder attention for boards with more than 128 tokens (up to 256), d_model 128, 4 heads: three kernels.
+//   qkv_rows_kernel  : token-wise LN1 + QKV projection over 64-row tiles of the flat row space.  Q and K are
+//                      written row-major; V is produced with swapped MFMA operands and written TRANSPOSED
+//                      ([sample][head][dim][token], token pitch 256) so that the attention core can load the
+//                      V^T fragments of the P.V product with plain 8-byte loads.
+//   attn_core_kernel : one wave per (sample, head), no LDS at all: K / V^T fragments live in registers for the
+//                      whole sample, scores are key-major so softmax is in-lane + two shuffles.
+//   proj_rows_kernel : token-wise output projection + residual over 64-row tiles.
+// The unfused tile-kernel path (QKV GEMM -> attention_kernel -> out-proj GEMM) stays as the fallback for other
+// widths.
+struct QkvRowsArgs {
+  const unsigned short* x;     // [rows, 128]
+  const unsigned short* wqkv;  // packed, Q pre-scaled by log2(e)/sqrt(32)
+  const float* bqkv;           // [384]
+  const float* ln_g;
+  const float* ln_b;
+  unsigned short* q;   // [rows, 128]
+  unsigned short* k;   // [rows, 128]
+  unsigned short* vt;  // [B][4][32][256]
+  int rows, HW;
+  float ln_eps;
+};
+
+__global__ __launch_bounds__(256, 3) void qkv_rows_kernel(QkvRowsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xn = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int row0 = blockIdx.x * kFfnRows;
+  const int nrows = min(kFfnRows, a.rows - row0);
+  const unsigned short* xg = a.x + (size_t)row0 * kD;
+  const short8* wq = reinterpret_cast<const short8*>(a.wqkv) + (size_t)wave * 128 + lane;
+  WFrags wa, wb;
+  load_wfrags(wa, wq);  // Q weights: in flight during staging and LayerNorm
+  {
+    uint4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256;
+      v[i] = make_uint4(0, 0, 0, 0);
+      if (c < nrows * 16) v[i] = *reinterpret_cast<const uint4*>(xg + (size_t)c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256;
+      *reinterpret_cast<uint4*>(xn + (c >> 4) * kStride + (c & 15) * 16) = v[i];
+    }
+  }
+  __syncthreads();
+  layernorm_rows(xn, nrows, a.ln_g, a.ln_b, a.ln_eps, tid);
+  __syncthreads();
+
+  const int ch0 = wave * 32 + q4 * 8;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {  // 0: Q, 1: K (weights as the A operand: lane = 8 channels of one token)
+    float bias[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[which * kD + ch0 + i];
+    float4v acc[kFfnTiles][2];
+#pragma unroll
+    for (int t = 0; t < kFfnTiles; ++t) {
+      acc[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
+      acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
+    }
+    if (which == 0) {
+      load_wfrags(wb, wq + (size_t)4 * 512);  // K weights fly during the Q GEMM
+      gemm_k128<false, kFfnTiles>(acc, wa, xn, l15, q4);
+      load_wfrags(wa, wq + (size_t)8 * 512);  // V weights fly during the K GEMM
+    } else {
+      gemm_k128<false, kFfnTiles>(acc, wb, xn, l15, q4);
+    }
+    unsigned short* dst = (which == 0 ? a.q : a.k) + (size_t)row0 * kD + ch0;
+#pragma unroll
+    for (int t = 0; t < kFfnTiles; ++t) {
+      int r = t * 16 + l15;
+      asm volatile("" : "+v"(r));
+      if (r < nrows) *reinterpret_cast<short8*>(dst + (size_t)r * kD) = pack8(acc[t][0], acc[t][1]);
+    }
+  }
+  {  // V with swapped operands: lane = 4 consecutive tokens of one channel -> one 8-byte store into V^T
+    const int dl = (l15 >> 2) * 8 + (l15 & 3);  // dim inside the head for n = 0 (n = 1 adds 4)
+    const float bv0 = a.bqkv[2 * kD + wave * 32 + dl], bv1 = a.bqkv[2 * kD + wave * 32 + dl + 4];
+    float4v acc[kFfnTiles][2];
+#pragma unroll
+    for (int t = 0; t < kFfnTiles; ++t) {
+      acc[t][0] = (float4v){bv0, bv0, bv0, bv0};
+      acc[t][1] = (float4v){bv1, bv1, bv1, bv1};
+    }
+    gemm_k128<true, kFfnTiles>(acc, wa, xn, l15, q4);
+#pragma unroll
+    for (int t = 0; t < kFfnTiles; ++t) {
+      int r = t * 16 + q4 * 4;  // first of this lane's 4 rows (HW % 4 == 0: they belong to one sample)
+      asm volatile("" : "+v"(r));
+      if (r >= nrows) continue;
+      const int grow = row0 + r;
+      const int b = grow / a.HW, tok = grow - b * a.HW;
+      unsigned short* vp = a.vt + (((size_t)b * 4 + wave) * 32 + dl) * 256 + tok;
+      uint2 lo, hi;
+      lo.x = pack_bf16x2(acc[t][0][0], acc[t][0][1]);
+      lo.y = pack_bf16x2(acc[t][0][2], acc[t][0][3]);
+      hi.x = pack_bf16x2(acc[t][1][0], acc[t][1][1]);
+      hi.y = pack_bf16x2(acc[t][1][2], acc[t][1][3]);
+      *reinterpret_cast<uint2*>(vp) = lo;
+      *reinterpret_cast<uint2*>(vp + 4 * 256) = hi;
+    }
+  }
+}
+
+struct AttnCoreArgs {
+  const unsigned short* q;   // [B*HW, 128]
+  const unsigned short* k;   // [B*HW, 128]
+  const unsigned short* vt;  // [B][4][32][256], columns >= HW hold finite values
+  unsigned short* out;       // [B*HW, 128]
+  int B, HW;
+};
+
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnCoreArgs a) {
+  const int lane = threadIdx.x & 63, head = threadIdx.x >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.x;
+  const int HW = a.HW;
+  const unsigned short* kb_ = a.k + (size_t)b * HW * kD + head * 32 + q4 * 8;
+  const unsigned short* qb_ = a.q + (size_t)b * HW * kD + head * 32 + q4 * 8;
+  short8 Kf[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int tok = min(kt * 16 + l15, HW - 1);  // padding keys re-read the last token (masked below)
+    Kf[kt] = *reinterpret_cast<const short8*>(kb_ + (size_t)tok * kD);
+  }
+  // V^T fragments: row = head dim (n*16 + l15), the lane's 8 key slots of block kb are keys 32kb+4q4..+3 and 32kb+16+4q4..+3
+  short8 VTf[NKT / 2][2];
+  const unsigned short* vb_ = a.vt + (((size_t)b * 4 + head) * 32 + l15) * 256 + q4 * 4;
+#pragma unroll
+  for (int kb = 0; kb < NKT / 2; ++kb)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const uint2 lo = *reinterpret_cast<const uint2*>(vb_ + (size_t)n * 16 * 256 + kb * 32);
+      const uint2 hi = *reinterpret_cast<const uint2*>(vb_ + (size_t)n * 16 * 256 + kb * 32 + 16);
+      uint4v u = {lo.x, lo.y, hi.x, hi.y};
+      VTf[kb][n] = __builtin_bit_cast(short8, u);
+    }
+  const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const int n_qt = (HW + 15) >> 4;
+  const int kt_full = HW >> 4;
+  unsigned short* ob_ = a.out + (size_t)b * HW * kD + head * 32 + q4 * 4;
+  for (int qt = 0; qt < n_qt; ++qt) {
+    const int qtok = min(qt * 16 + l15, HW - 1);
+    const short8 Qf = *reinterpret_cast<const short8*>(qb_ + (size_t)qtok * kD);
+    float4v st[NKT];
+    float m = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt], Qf, (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      if (kt >= kt_full) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st[kt][j] = __builtin_amdgcn_exp2f(st[kt][j] - m);
+    float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f}, os = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NKT / 2; ++kb) {
+      const short8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][0], pf, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][1], pf, o1, 0, 0, 0);
+      os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
+    }
+    const float inv = 1.0f / os[0];
+    // lane holds dims 4q4..4q4+3 (o0) and 16+4q4..+3 (o1) of query qt*16 + l15
+    if (qt * 16 + l15 < HW) {
+      uint2 lo, hi;
+      lo.x = pack_bf16x2(o0[0] * inv, o0[1] * inv);
+      lo.y = pack_bf16x2(o0[2] * inv, o0[3] * inv);
+      hi.x = pack_bf16x2(o1[0] * inv, o1[1] * inv);
+      hi.y = pack_bf16x2(o1[2] * inv, o1[3] * inv);
+      unsigned short* op = ob_ + (size_t)(qt * 16 + l15) * kD;
+      *reinterpret_cast<uint2*>(op) = lo;
+      *reinterpret_cast<uint2*>(op + 16) = hi;
+    }
+  }
+}
+
+struct ProjRowsArgs {
+  const unsigned short* in;        // [rows, 128] attention output
+  const unsigned short* residual;  // [rows, 128]
+  const unsigned short* w;         // packed 128 -> 128
+  const float* bias;               // [128]
+  unsigned short* out;             // [rows, 128]
+  int rows;
+};
+
+__global__ __launch_bounds__(256, 3) void proj_rows_kernel(ProjRowsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int row0 = blockIdx.x * kFfnRows;
+  const int nrows = min(kFfnRows, a.rows - row0);
+  const unsigned short* ig = a.in + (size_t)row0 * kD;
+  WFrags w;
+  load_wfrags(w, reinterpret_cast<const short8*>(a.w) + (size_t)wave * 128 + lane);
+  const int ch0 = wave * 32 + q4 * 8;
+  ResFragsT<kFfnTiles> res;
+  load_residual(res, a.residual + (size_t)row0 * kD + ch0, nrows, l15);
+  {
+    uint4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256;
+      v[i] = make_uint4(0, 0, 0, 0);
+      if (c < nrows * 16) v[i] = *reinterpret_cast<const uint4*>(ig + (size_t)c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256;
+      *reinterpret_cast<uint4*>(smem + (c >> 4) * kStride + (c & 15) * 16) = v[i];
+    }
+  }
+  __syncthreads();
+  float bias[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bias[i] = a.bias[ch0 + i];
+  float4v acc[kFfnTiles][2];
+#pragma unroll
+  for (int t = 0; t < kFfnTiles; ++t) {
+    acc[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
+    acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
+  }
+  gemm_k128<false, kFfnTiles>(acc, w, smem, l15, q4);
+  unsigned short* og = a.out + (size_t)row0 * kD;
+#pragma unroll
+  for (int t = 0; t < kFfnTiles; ++t) {
+    int r = t * 16 + l15;
+    asm volatile("" : "+v"(r));
+    if (r >= nrows) continue;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = acc[t][0][j] + bf16_to_float((unsigned short)res.r[t][j]);
+      o[4 + j] = acc[t][1][j] + bf16_to_float((unsigned short)res.r[t][4 + j]);
+    }
+    *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+  }
+}
+
 extern "C" {
 
 int atri_attn_block(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
@@ -496,6 +750,33 @@ int atri_ffn_block(const void* y, void* out, const void* w1, const float* b1, co
     case 4: return launch_ffn<4>(a, stream);
     default: return -12;
   }
+}
+
+// Attention half of an encoder layer for up to 256 tokens (d_model 128, 4 heads, HW % 4 == 0):
+// y = x + OutProj(MHA(LayerNorm1(x))).  q, k: scratch [B*HW, 128]; vt: scratch [B, 4, 32, 256] whose columns
+// >= HW must hold finite values (allocate zero-filled once); att: scratch [B*HW, 128].
+int atri_attn_rows(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                   const float* ln_g, const float* ln_b, void* q, void* k, void* vt, void* att, int B, int HW, int D,
+                   int heads, float ln_eps, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (D != kD || heads != 4 || HW < 1 || HW > 256 || (HW & 3) != 0) return -10;
+  const int rows = B * HW;
+  const int blocks = (rows + kFfnRows - 1) / kFfnRows;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)qkv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnTileBytes);
+    (void)hipFuncSetAttribute((const void*)proj_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnTileBytes);
+    attr = true;
+  }
+  QkvRowsArgs qa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, ln_g, ln_b, (unsigned short*)q,
+                 (unsigned short*)k, (unsigned short*)vt, rows, HW, ln_eps};
+  hipLaunchKernelGGL(qkv_rows_kernel, dim3(blocks), dim3(256), kFfnTileBytes, stream, qa);
+  AttnCoreArgs ca{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)vt, (unsigned short*)att, B, HW};
+  if (HW <= 128) hipLaunchKernelGGL(attn_core_kernel<8>, dim3(B), dim3(256), 0, stream, ca);
+  else hipLaunchKernelGGL(attn_core_kernel<16>, dim3(B), dim3(256), 0, stream, ca);
+  ProjRowsArgs pa{(const unsigned short*)att, (const unsigned short*)x, (const unsigned short*)wo, bo, (unsigned short*)out, rows};
+  hipLaunchKernelGGL(proj_rows_kernel, dim3(blocks), dim3(256), kFfnTileBytes, stream, pa);
+  return (int)hipGetLastError();
 }
 
 }  // extern "C"

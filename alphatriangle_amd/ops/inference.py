@@ -15,6 +15,7 @@ Layer -> kernel map (default config, B leaves, HW = 120 tokens):
   1x1 projections, QKV, out-proj, FFN    tile_gemm_kernel taps=1  (+LayerNorm prologue,
                                          residual / activation / positional epilogue)
   4-head attention                       attention_kernel         (MFMA, softmax in registers)
+  encoder layer, d_model 128, 129..256 tok qkv_rows_kernel + attn_core_kernel + proj_rows_kernel + ffn_block_kernel
   encoder layer, d_model 128 / <=128 tok attn_block_kernel + ffn_block_kernel (tf_kernels.hip; replaces the
                                          five launches above with two, activations stay in LDS / registers)
   final LayerNorm + flatten + shared FC  fc_rows_splitk_kernel (128-channel bodies: LN applied while staging the
@@ -216,6 +217,12 @@ class InferenceEngine:
             self.uses_tf and model_config.TRANSFORMER_DIM == 128 and model_config.TRANSFORMER_FC_DIM % 128 == 0
             and model_config.TRANSFORMER_FC_DIM <= 512
         )
+        # attention half for boards the one-workgroup-per-sample kernel cannot hold (129..256 tokens): row-tiled QKV / out-proj
+        # kernels around a register-resident attention core
+        self.rows_attn = bool(
+            self.uses_tf and not self.fused_tf and model_config.TRANSFORMER_DIM == 128 and model_config.TRANSFORMER_HEADS == 4
+            and self.HW <= 256 and self.HW % 4 == 0
+        )
         self.use_rowconv = True  # tests flip this to cover the generic tile kernel on small boards
         self._store: list[torch.Tensor] = []
         self._store_cursor = 0
@@ -362,6 +369,7 @@ class InferenceEngine:
         self.bufs = [torch.empty(rows * maxc, dtype=torch.bfloat16, device=dev) for _ in range(5)]
         self.fc_in = None if self.fc_fused else torch.zeros(batch, self.fc_kp, dtype=torch.bfloat16, device=dev)
         self.other_bf16 = torch.zeros(batch, self.other_pad, dtype=torch.bfloat16, device=dev)
+        self.vt = torch.zeros(batch * 4 * 32 * 256, dtype=torch.bfloat16, device=dev) if self.rows_attn else None
         self.slabs = torch.empty(self.fc_sk, batch, 128, dtype=torch.float32, device=dev)
         dense_w = max([self.fc_n] + [l.cout for l in self.shared_rest + self.policy_layers + self.value_layers])
         self.dense = [torch.empty(batch * dense_w, dtype=torch.bfloat16, device=dev) for _ in range(3)]
@@ -464,9 +472,15 @@ class InferenceEngine:
                             hb.i32(D), hb.i32(ff1.cout), hb.i32(self.act), hb.f32(ff1.ln_eps))
                     x = q
                     continue
-                self._run_gemm(tl["qkv"], bufs[x], bufs[q], rows, conv=True)
-                hb.call("atri_attention", hb.ptr(bufs[q]), hb.ptr(bufs[t]), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads))
-                self._run_gemm(tl["out"], bufs[t], bufs[y], rows, conv=True, residual=bufs[x])
+                if self.rows_attn:
+                    qkv, out = tl["qkv"], tl["out"]
+                    hb.call("atri_attn_rows", hb.ptr(bufs[x]), hb.ptr(bufs[y]), hb.ptr(qkv.w), hb.ptr(qkv.bias), hb.ptr(out.w),
+                            hb.ptr(out.bias), hb.ptr(qkv.ln_g), hb.ptr(qkv.ln_b), hb.ptr(bufs[q]), hb.ptr(bufs[t]), hb.ptr(self.vt),
+                            hb.ptr(bufs[h]), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads), hb.f32(qkv.ln_eps))
+                else:
+                    self._run_gemm(tl["qkv"], bufs[x], bufs[q], rows, conv=True)
+                    hb.call("atri_attention", hb.ptr(bufs[q]), hb.ptr(bufs[t]), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads))
+                    self._run_gemm(tl["out"], bufs[t], bufs[y], rows, conv=True, residual=bufs[x])
                 if self.fused_ffn:
                     ff1, ff2 = tl["ff1"], tl["ff2"]
                     hb.call("atri_ffn_block", hb.ptr(bufs[y]), hb.ptr(bufs[q]), hb.ptr(ff1.w), hb.ptr(ff1.bias),

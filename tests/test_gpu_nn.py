@@ -286,3 +286,48 @@ def test_rowconv_and_tile_gemm_paths_agree():
     torch.cuda.synchronize()
     assert (l1 - l2).abs().max().item() < 0.05
     assert (v1 - v2).abs().max().item() < 0.1
+
+
+@pytest.mark.parametrize("hw", [252, 120, 64])
+def test_rows_attention_path_matches_torch(hw):
+    """qkv_rows + attn_core + proj_rows (+ ffn_block) vs nn.TransformerEncoderLayer(norm_first=True) in fp32."""
+    from alphatriangle_amd.ops import hipbind as hb
+    from alphatriangle_amd.ops.inference import pack_gemm_weights
+
+    torch.manual_seed(9)
+    dev = _dev()
+    B, D, Fd, heads = 5, 128, 256, 4
+    layer = torch.nn.TransformerEncoderLayer(D, heads, Fd, dropout=0.0, activation="relu", batch_first=True, norm_first=True).to(dev).eval()
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(_bf16_round(p + 0.05 * torch.randn_like(p)))
+    x = _bf16_round(torch.randn(B, hw, D, device=dev))
+    with torch.no_grad():
+        ref_y = x + layer._sa_block(layer.norm1(x), None, None)
+        ref_z = layer(x)
+
+    def pk(w_nk):
+        return pack_gemm_weights(w_nk.detach().float().t().unsqueeze(0).contiguous(), dev)[0]
+
+    w_in = layer.self_attn.in_proj_weight.detach().float().clone()
+    b_in = layer.self_attn.in_proj_bias.detach().float().clone()
+    w_in[:D] *= math.log2(math.e) / math.sqrt(32)
+    b_in[:D] *= math.log2(math.e) / math.sqrt(32)
+    xb = x.to(torch.bfloat16).contiguous()
+    y, z = torch.zeros_like(xb), torch.zeros_like(xb)
+    q, k, att = torch.zeros_like(xb), torch.zeros_like(xb), torch.zeros_like(xb)
+    vt = torch.zeros(B * 4 * 32 * 256, dtype=torch.bfloat16, device=dev)
+    w_qkv, w_o, w_1, w_2 = pk(w_in), pk(layer.self_attn.out_proj.weight), pk(layer.linear1.weight), pk(layer.linear2.weight)
+    b_o = layer.self_attn.out_proj.bias.detach().float().contiguous()
+    g1, be1 = layer.norm1.weight.detach().float().contiguous(), layer.norm1.bias.detach().float().contiguous()
+    g2, be2 = layer.norm2.weight.detach().float().contiguous(), layer.norm2.bias.detach().float().contiguous()
+    b1, b2 = layer.linear1.bias.detach().float().contiguous(), layer.linear2.bias.detach().float().contiguous()
+    hb.call("atri_attn_rows", hb.ptr(xb), hb.ptr(y), hb.ptr(w_qkv), hb.ptr(b_in), hb.ptr(w_o), hb.ptr(b_o), hb.ptr(g1), hb.ptr(be1),
+            hb.ptr(q), hb.ptr(k), hb.ptr(vt), hb.ptr(att), hb.i32(B), hb.i32(hw), hb.i32(D), hb.i32(heads), hb.f32(layer.norm1.eps))
+    hb.call("atri_ffn_block", hb.ptr(y), hb.ptr(z), hb.ptr(w_1), hb.ptr(b1), hb.ptr(w_2), hb.ptr(b2), hb.ptr(g2), hb.ptr(be2),
+            hb.i32(B), hb.i32(hw), hb.i32(D), hb.i32(Fd), hb.i32(1), hb.f32(layer.norm2.eps))
+    torch.cuda.synchronize()
+    yerr = (y.float() - ref_y).abs().max().item()
+    zerr = (z.float() - ref_z).abs().max().item()
+    assert yerr < 0.06, f"attention half err {yerr}"
+    assert zerr < 0.08, f"layer err {zerr}"
