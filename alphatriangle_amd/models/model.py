@@ -25,7 +25,7 @@ class GemmConv2d(nn.Conv2d):
 
     On gfx950 MIOpen has no tuned bf16 / fp32 convolution for these tiny 8x15 images and falls
     back to naive kernels (11 ms for one weight-gradient call at batch 256).  Lowering the
-    convolution to ``unfold`` + one batched matmul puts forward, data-gradient and
+    convolution to a patch matrix + one batched matmul puts forward, data-gradient and
     weight-gradient on hipBLASLt GEMMs, which is what the learner needs.  CPU tensors keep the
     stock implementation.
     """
@@ -47,7 +47,11 @@ class GemmConv2d(nn.Conv2d):
         if kh == 1 and kw == 1 and ph == 0 and pw == 0:
             cols = x.reshape(b, x.shape[1], h * w)
         else:
-            cols = torch.nn.functional.unfold(x, (kh, kw), padding=(ph, pw))  # [B, Cin*kh*kw, oh*ow]
+            # F.unfold launches one im2col kernel PER SAMPLE (1536 launches per step at batch 256); strided views of the
+            # padded input plus one gathering copy build the same [B, Cin*kh*kw, oh*ow] matrix in two launches
+            xp = torch.nn.functional.pad(x, (pw, pw, ph, ph))
+            patches = xp.unfold(2, kh, 1).unfold(3, kw, 1)  # [B, Cin, oh, ow, kh, kw] (view)
+            cols = patches.permute(0, 1, 4, 5, 2, 3).reshape(b, x.shape[1] * kh * kw, oh * ow)
         out = torch.matmul(self.weight.reshape(self.out_channels, -1), cols)  # [B, Cout, oh*ow]
         if self.bias is not None:
             out = out + self.bias.view(1, -1, 1)
