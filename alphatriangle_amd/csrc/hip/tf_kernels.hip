@@ -76,17 +76,27 @@ __device__ __forceinline__ void layernorm_rows(unsigned char* lds, int HW, const
   const float mean = s * (1.0f / kD);
   const float rstd = rsqrtf(fmaxf(ss * (1.0f / kD) - mean * mean, 0.f) + eps);
   if (live) {
+    if (g == nullptr) {  // affine part folded into the following GEMM's weights and bias by the host
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float4* gp = reinterpret_cast<const float4*>(g + (c0 + c) * 8);
-      const float4* bp = reinterpret_cast<const float4*>(b + (c0 + c) * 8);
-      const float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
-      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      float o[8];
+      for (int c = 0; c < 8; ++c) {
+        float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (bf16_to_float((unsigned short)v[c][j]) - mean) * rstd * gg[j] + bb[j];
-      *reinterpret_cast<short8*>(rowp + c * 16) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_to_float((unsigned short)v[c][j]) - mean) * rstd;
+        *reinterpret_cast<short8*>(rowp + c * 16) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float4* gp = reinterpret_cast<const float4*>(g + (c0 + c) * 8);
+        const float4* bp = reinterpret_cast<const float4*>(b + (c0 + c) * 8);
+        const float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_to_float((unsigned short)v[c][j]) - mean) * rstd * gg[j] + bb[j];
+        *reinterpret_cast<short8*>(rowp + c * 16) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+      }
     }
   }
 }
@@ -178,6 +188,9 @@ struct AttnBlockArgs {
   float ln_eps;
 };
 
+// DBG != 0 instantiations are roofline probes (bench/attn_probe.py), bit mask: 1 no LayerNorm, 2 no K/V/Q GEMMs,
+// 4 no attention loop, 8 no output projection, 16 no input staging, 32 no output stores.
+template <int DBG>
 __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xn = smem;
@@ -191,11 +204,11 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   const short8* wq = reinterpret_cast<const short8*>(a.wqkv) + (size_t)wave * 128 + lane;
   WFrags wa, wb;
   load_wfrags(wa, wq + (size_t)4 * 512);  // K weights: in flight during staging and LayerNorm
-  stage_tile(xg, xn, HW, tid);
+  if (!(DBG & 16)) stage_tile(xg, xn, HW, tid);
   // rows >= HW of the attention-output tile are padding for the out-projection: keep them finite
   for (int c = tid + HW * 16; c < kRows * 16; c += 256) *reinterpret_cast<uint4*>(ao + (c >> 4) * kStride + (c & 15) * 16) = make_uint4(0, 0, 0, 0);
   __syncthreads();
-  layernorm_rows(xn, HW, a.ln_g, a.ln_b, a.ln_eps, tid);
+  if (!(DBG & 1)) layernorm_rows(xn, HW, a.ln_g, a.ln_b, a.ln_eps, tid);
   __syncthreads();
 
   short8 Qf[8], Kf[8], VTf[4][2];
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
       acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
     }
     load_wfrags(wb, wq + (size_t)8 * 512);  // V weights fly during the K GEMM
-    gemm_k128<false>(acc, wa, xn, l15, q4);
+    if (!(DBG & 2)) gemm_k128<false>(acc, wa, xn, l15, q4);
 #pragma unroll
     for (int t = 0; t < 8; ++t) Kf[t] = pack8(acc[t][0], acc[t][1]);
   }
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
       acc[t][1] = (float4v){bv1, bv1, bv1, bv1};
     }
     load_wfrags(wa, wq);  // Q weights fly during the V GEMM
-    gemm_k128<true>(acc, wb, xn, l15, q4);
+    if (!(DBG & 2)) gemm_k128<true>(acc, wb, xn, l15, q4);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       VTf[kb][0] = pack8(acc[2 * kb][0], acc[2 * kb + 1][0]);
@@ -244,13 +257,13 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
       acc[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
       acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
     }
-    gemm_k128<false>(acc, wa, xn, l15, q4);
+    if (!(DBG & 2)) gemm_k128<false>(acc, wa, xn, l15, q4);
 #pragma unroll
     for (int t = 0; t < 8; ++t) Qf[t] = pack8(acc[t][0], acc[t][1]);
   }
   load_wfrags(wb, reinterpret_cast<const short8*>(a.wo) + (size_t)wave * 128 + lane);  // out-proj weights fly during attention
   // ---- attention of head `wave`, one 16-query tile at a time
-  const int n_qt = (HW + 15) >> 4;
+  const int n_qt = (DBG & 4) ? 0 : (HW + 15) >> 4;
   const int kt_full = HW >> 4;  // key tiles below this index hold no padding
   const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
 #pragma unroll
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   float4v acc[8][2];
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
-  gemm_k128<false>(acc, wb, ao, l15, q4);
+  if (!(DBG & 8)) gemm_k128<false>(acc, wb, ao, l15, q4);
   float bias[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bias[i] = a.bo[ch0 + i];
@@ -315,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
     int r = t * 16 + l15;
     asm volatile("" : "+v"(r));
     if (r >= HW) continue;
+    if ((DBG & 32) && acc[t][0][0] != 12345.f) continue;
     float o[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -451,6 +465,17 @@ __global__ __launch_bounds__(256, 3) void ffn_block_kernel(FfnBlockArgs a) {
 }
 
 namespace {
+template <int DBG>
+int launch_attn(const AttnBlockArgs& a, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_block_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_block_kernel<DBG>, dim3(a.B), dim3(256), 2 * kTileBytes, stream, a);
+  return (int)hipGetLastError();
+}
+
 template <int HALVES>
 int launch_ffn(const FfnBlockArgs& a, hipStream_t stream) {
   static bool attr = false;
@@ -719,20 +744,36 @@ __global__ __launch_bounds__(256, 3) void proj_rows_kernel(ProjRowsArgs a) {
 
 extern "C" {
 
+static int attn_block_impl(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                           const float* ln_g, const float* ln_b, int B, int HW, int D, int heads, float ln_eps, int dbg,
+                           hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (D != kD || heads != 4 || HW > kRows || HW < 1) return -10;
+  AttnBlockArgs a{(const unsigned short*)x, (unsigned short*)out, (const unsigned short*)wqkv, bqkv,
+                  (const unsigned short*)wo, bo, ln_g, ln_b, B, HW, ln_eps};
+  switch (dbg) {
+    case 0: return launch_attn<0>(a, stream);
+    case 1: return launch_attn<1>(a, stream);
+    case 2: return launch_attn<2>(a, stream);
+    case 4: return launch_attn<4>(a, stream);
+    case 8: return launch_attn<8>(a, stream);
+    case 15: return launch_attn<15>(a, stream);
+    case 47: return launch_attn<47>(a, stream);
+    case 63: return launch_attn<63>(a, stream);
+    default: return -14;
+  }
+}
+
 int atri_attn_block(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
                     const float* ln_g, const float* ln_b, int B, int HW, int D, int heads, float ln_eps,
                     hipStream_t stream) {
-  if (B <= 0) return 0;
-  if (D != kD || heads != 4 || HW > kRows || HW < 1) return -10;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
-    attr = true;
-  }
-  AttnBlockArgs a{(const unsigned short*)x, (unsigned short*)out, (const unsigned short*)wqkv, bqkv,
-                  (const unsigned short*)wo, bo, ln_g, ln_b, B, HW, ln_eps};
-  hipLaunchKernelGGL(attn_block_kernel, dim3(B), dim3(256), 2 * kTileBytes, stream, a);
-  return (int)hipGetLastError();
+  return attn_block_impl(x, out, wqkv, bqkv, wo, bo, ln_g, ln_b, B, HW, D, heads, ln_eps, 0, stream);
+}
+
+// Roofline probe: the same launch with phases removed (see the kernel's DBG parameter).
+int atri_attn_block_probe(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                          const float* ln_g, const float* ln_b, int B, int HW, int dbg, hipStream_t stream) {
+  return attn_block_impl(x, out, wqkv, bqkv, wo, bo, ln_g, ln_b, B, HW, kD, 4, 1e-5f, dbg, stream);
 }
 
 int atri_ffn_block(const void* y, void* out, const void* w1, const float* b1, const void* w2, const float* b2,

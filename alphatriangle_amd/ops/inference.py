@@ -210,7 +210,7 @@ class InferenceEngine:
         # one-workgroup-per-sample fused encoder-layer kernels (csrc/hip/tf_kernels.hip)
         self.fused_tf = bool(
             self.uses_tf and model_config.TRANSFORMER_DIM == 128 and model_config.TRANSFORMER_HEADS == 4
-            and self.HW <= 128 and model_config.TRANSFORMER_FC_DIM % 128 == 0
+            and self.HW <= 128
         )
         # the FFN half of an encoder layer is token-wise: its fused kernel is tiled over flat rows and works for any board
         self.fused_ffn = bool(
@@ -302,21 +302,35 @@ class InferenceEngine:
             else:
                 raise ValueError("transformer directly on the first conv layer is not supported")
             hd = D // mc.TRANSFORMER_HEADS
+            # The fused / row-tiled encoder kernels only normalise; LayerNorm's affine part is folded into the
+            # following projection: (xhat * g + b) W = xhat (g (.) W) + b W.  The tile-kernel fallback keeps g / b.
+            fold_attn = self.fused_tf or self.rows_attn
+            fold_ffn = self.fused_ffn
             for layer in model.transformer_body.layers:
                 w_in = layer.self_attn.in_proj_weight.detach().float().clone()  # [3D, D]
                 b_in = layer.self_attn.in_proj_bias.detach().float().clone()
+                g1, be1 = layer.norm1.weight.detach().float(), layer.norm1.bias.detach().float()
+                if fold_attn:
+                    b_in = b_in + w_in @ be1
+                    w_in = w_in * g1[None, :]
                 qscale = math.log2(math.e) / math.sqrt(hd)  # the kernels' softmax is exp2-based
                 w_in[:D] *= qscale
                 b_in[:D] *= qscale
                 qkv = self._gemm(
                     w_in.t().unsqueeze(0).contiguous(), b_in, 0,
-                    ln_g=layer.norm1.weight.detach().float().to(dev), ln_b=layer.norm1.bias.detach().float().to(dev),
+                    ln_g=None if fold_attn else g1.to(dev), ln_b=None if fold_attn else be1.to(dev),
                     ln_eps=float(layer.norm1.eps),
                 )
                 out = self._linear_layer(layer.self_attn.out_proj, None, 0)
-                ff1 = self._linear_layer(
-                    layer.linear1, None, self.act,
-                    ln_g=layer.norm2.weight.detach().float().to(dev), ln_b=layer.norm2.bias.detach().float().to(dev),
+                w1 = layer.linear1.weight.detach().float().clone()  # [F, D]
+                b1 = layer.linear1.bias.detach().float().clone()
+                g2, be2 = layer.norm2.weight.detach().float(), layer.norm2.bias.detach().float()
+                if fold_ffn:
+                    b1 = b1 + w1 @ be2
+                    w1 = w1 * g2[None, :]
+                ff1 = self._gemm(
+                    w1.t().unsqueeze(0).contiguous(), b1, self.act,
+                    ln_g=None if fold_ffn else g2.to(dev), ln_b=None if fold_ffn else be2.to(dev),
                     ln_eps=float(layer.norm2.eps),
                 )
                 ff2 = self._linear_layer(layer.linear2, None, 0)
@@ -462,33 +476,28 @@ class InferenceEngine:
             for tl in self.tf_layers:
                 free = [i for i in range(5) if i != x]
                 q, t, y, h = free[0], free[1], free[2], free[3]
+                qkv, out, ff1, ff2 = tl["qkv"], tl["out"], tl["ff1"], tl["ff2"]
+                # ---- attention half: bufs[x] -> bufs[y]
                 if self.fused_tf:
-                    qkv, out, ff1, ff2 = tl["qkv"], tl["out"], tl["ff1"], tl["ff2"]
                     hb.call("atri_attn_block", hb.ptr(bufs[x]), hb.ptr(bufs[y]), hb.ptr(qkv.w), hb.ptr(qkv.bias),
                             hb.ptr(out.w), hb.ptr(out.bias), hb.ptr(qkv.ln_g), hb.ptr(qkv.ln_b), hb.i32(B), hb.i32(self.HW),
                             hb.i32(D), hb.i32(heads), hb.f32(qkv.ln_eps))
-                    hb.call("atri_ffn_block", hb.ptr(bufs[y]), hb.ptr(bufs[q]), hb.ptr(ff1.w), hb.ptr(ff1.bias),
-                            hb.ptr(ff2.w), hb.ptr(ff2.bias), hb.ptr(ff1.ln_g), hb.ptr(ff1.ln_b), hb.i32(B), hb.i32(self.HW),
-                            hb.i32(D), hb.i32(ff1.cout), hb.i32(self.act), hb.f32(ff1.ln_eps))
-                    x = q
-                    continue
-                if self.rows_attn:
-                    qkv, out = tl["qkv"], tl["out"]
+                elif self.rows_attn:
                     hb.call("atri_attn_rows", hb.ptr(bufs[x]), hb.ptr(bufs[y]), hb.ptr(qkv.w), hb.ptr(qkv.bias), hb.ptr(out.w),
                             hb.ptr(out.bias), hb.ptr(qkv.ln_g), hb.ptr(qkv.ln_b), hb.ptr(bufs[q]), hb.ptr(bufs[t]), hb.ptr(self.vt),
                             hb.ptr(bufs[h]), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads), hb.f32(qkv.ln_eps))
                 else:
-                    self._run_gemm(tl["qkv"], bufs[x], bufs[q], rows, conv=True)
+                    self._run_gemm(qkv, bufs[x], bufs[q], rows, conv=True)
                     hb.call("atri_attention", hb.ptr(bufs[q]), hb.ptr(bufs[t]), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads))
-                    self._run_gemm(tl["out"], bufs[t], bufs[y], rows, conv=True, residual=bufs[x])
+                    self._run_gemm(out, bufs[t], bufs[y], rows, conv=True, residual=bufs[x])
+                # ---- FFN half: bufs[y] -> bufs[q]
                 if self.fused_ffn:
-                    ff1, ff2 = tl["ff1"], tl["ff2"]
                     hb.call("atri_ffn_block", hb.ptr(bufs[y]), hb.ptr(bufs[q]), hb.ptr(ff1.w), hb.ptr(ff1.bias),
                             hb.ptr(ff2.w), hb.ptr(ff2.bias), hb.ptr(ff1.ln_g), hb.ptr(ff1.ln_b), hb.i32(B), hb.i32(self.HW),
                             hb.i32(D), hb.i32(ff1.cout), hb.i32(self.act), hb.f32(ff1.ln_eps))
                 else:
-                    self._run_gemm(tl["ff1"], bufs[y], bufs[h], rows, conv=True)
-                    self._run_gemm(tl["ff2"], bufs[h], bufs[q], rows, conv=True, residual=bufs[y])
+                    self._run_gemm(ff1, bufs[y], bufs[h], rows, conv=True)
+                    self._run_gemm(ff2, bufs[h], bufs[q], rows, conv=True, residual=bufs[y])
                 x = q
             cur = x
             ln = self.final_ln

@@ -137,6 +137,9 @@ def test_engine_forward_matches_pytorch_module(preset):
                 m.running_var.uniform_(0.5, 1.5)
                 m.weight.uniform_(0.5, 1.5)
                 m.bias.normal_(0, 0.2)
+            if isinstance(m, torch.nn.LayerNorm):  # non-trivial affine parts: they get folded into the next projection
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.normal_(0, 0.2)
     net.sync_inference_weights()
     B = 37
     grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
@@ -219,12 +222,17 @@ def test_fused_and_unfused_encoder_paths_agree():
     other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
     l1, v1 = eng.forward(grid, other)
     l1, v1 = l1.clone(), v1.clone()
+    # the fused kernels get LayerNorm's affine part folded into their weights, so a path switch needs a re-pack
     eng.fused_tf = False
+    eng.fused_ffn = False
+    net.sync_inference_weights()
     try:
         l2, v2 = eng.forward(grid, other)
         l2, v2 = l2.clone(), v2.clone()
     finally:
         eng.fused_tf = True
+        eng.fused_ffn = True
+        net.sync_inference_weights()
     torch.cuda.synchronize()
     assert (l1 - l2).abs().max().item() < 0.05
     assert (v1 - v2).abs().max().item() < 0.1
