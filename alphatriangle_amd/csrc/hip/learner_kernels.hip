@@ -9,6 +9,8 @@
 //   PER         alphatriangle/utils/sumtree.py:25-98, alphatriangle/rl/core/buffer.py:96-195
 #include "common.hpp"
 
+#include <vector>
+
 using namespace atrihip;
 
 // ---------------------------------------------------------------------------
@@ -296,6 +298,31 @@ int atri_per_priorities(double* tree, long long P, const int* idx, const float* 
   hipLaunchKernelGGL(per_priorities_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tree, P, idx, err, n, alpha, eps,
                      max_prio);
   return (int)hipGetLastError();
+}
+
+// Node census of a captured (not yet instantiated) HIP graph: counts[0] = kernel nodes, counts[1] = memset nodes,
+// counts[2] = every other node type.  Memset nodes recorded by library calls do not replay reliably, so callers
+// refuse to replay a graph that holds any.
+int atri_graph_census(void* graph, int* counts, hipStream_t) {
+  hipGraph_t g = (hipGraph_t)graph;
+  size_t n = 0;
+  hipError_t e = hipGraphGetNodes(g, nullptr, &n);
+  if (e != hipSuccess) return (int)e;
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n) {
+    e = hipGraphGetNodes(g, nodes.data(), &n);
+    if (e != hipSuccess) return (int)e;
+  }
+  counts[0] = counts[1] = counts[2] = 0;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    e = hipGraphNodeGetType(nodes[i], &t);
+    if (e != hipSuccess) return (int)e;
+    if (t == hipGraphNodeTypeKernel) ++counts[0];
+    else if (t == hipGraphNodeTypeMemset) ++counts[1];
+    else ++counts[2];
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -9,10 +9,17 @@ MI355X path: batches arrive as device tensors straight from the HBM replay
 (:class:`TensorBatch`), the loss is one fused HIP kernel, the parameters live in a
 flat buffer updated by one fused kernel, and with data-parallel learners a single
 RCCL all-reduce of the flat gradient buffer runs between backward and the update.
+With ``TrainConfig.COMPILE_MODEL`` the zero-grad + forward + loss + backward part of
+the step (several hundred launches) is captured once into a HIP graph and replayed
+when the graph passes its guards (:class:`GraphedForwardBackward`); the all-reduce
+and the optimizer kernels stay eager, so the learning rate and Adam bias corrections
+remain ordinary host scalars.  The step is GPU-bound (7.37 ms eager and replayed at
+batch 256 on one MI355X), so the switch is off by default.
 """
 
 from __future__ import annotations
 
+import ctypes as C
 import logging
 from collections.abc import Callable
 from dataclasses import dataclass
@@ -25,7 +32,8 @@ from torch.optim.lr_scheduler import CosineAnnealingLR, StepLR, _LRScheduler
 from ...config.env_config import EnvConfig
 from ...config.train_config import TrainConfig
 from ...models.network import NeuralNetwork
-from ...ops.losses import alphazero_loss, c51_two_hot
+from ...ops import hipbind as hb
+from ...ops.losses import LossOutputs, alphazero_loss, c51_two_hot
 from ...ops.optim import FlatParameterSpace, build_optimizer
 from ...utils.types import ExperienceBatch, PERBatchSample
 
@@ -47,6 +55,106 @@ class TensorBatch:
         return int(self.grid.shape[0])
 
 
+class GraphedForwardBackward:
+    """Zero-grad + forward + loss + backward for one fixed batch shape as a replayable HIP graph.
+
+    The graph reads five static input tensors and leaves the gradients in the flat gradient
+    buffer plus five static outputs (total / policy / value loss, entropy, per-sample TD errors).
+    Two guards decide whether it is ever replayed.  Structural: library reductions that spread
+    over many blocks (the bias-gradient column sums of the encoder's linear layers are the case
+    in this network) record memset nodes for their semaphores, and such nodes do not replay
+    reliably (a NaN in one bias-gradient element on the second new batch was the observed
+    symptom), so a graph whose node census shows any memset node is refused outright.
+    Numerical: the graph is replayed ``checks`` times, with eager forward/backward passes and
+    device synchronisations in between, from the same parameters, BatchNorm buffers and RNG
+    state as an eager pass (the graph-safe Philox state makes dropout masks identical), and
+    every replay has to reproduce the eager gradients.  A refused graph leaves the trainer eager.
+    """
+
+    def __init__(self, trainer: "Trainer", tb: TensorBatch, *, warmup: int = 3, checks: int = 3, tol: float = 2e-2):
+        self.trainer = trainer
+        self.shape = tuple(tb.grid.shape)
+        self.inputs = TensorBatch(tb.grid.clone(), tb.other.clone(), tb.policy_target.clone(), tb.returns.clone(), tb.weights.clone())
+        self.outputs: tuple[torch.Tensor, ...] = ()
+        self.graph: torch.cuda.CUDAGraph | None = None
+        self.max_rel_err = float("nan")
+        self.kernel_nodes = self.memset_nodes = self.other_nodes = 0
+        model = trainer.model
+        flat = trainer.flat
+        assert flat is not None
+        buffers = [b for b in model.buffers()]
+        saved = [b.clone() for b in buffers]
+
+        def restore() -> None:
+            for b, s in zip(buffers, saved, strict=True):
+                b.copy_(s)
+
+        side = torch.cuda.Stream()  # default priority
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                trainer._forward_backward(self.inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        restore()
+        graph = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(graph):
+            out = trainer._forward_backward(self.inputs)
+            self.outputs = (out.total.detach(), out.policy_loss, out.value_loss, out.entropy, out.td_errors)
+        del out
+        restore()
+        census = (C.c_int * 3)()
+        hb.call("atri_graph_census", C.c_void_p(graph.raw_cuda_graph()), census)
+        self.kernel_nodes, self.memset_nodes, self.other_nodes = int(census[0]), int(census[1]), int(census[2])
+        if self.memset_nodes > 0:
+            logger.warning(
+                "Learner HIP graph holds %d memset nodes (next to %d kernel nodes); not replaying it, staying eager.",
+                self.memset_nodes, self.kernel_nodes,
+            )
+            return
+        graph.instantiate()
+        worst = 0.0
+        for _ in range(checks):
+            rng = torch.cuda.get_rng_state(tb.grid.device)
+            ref = trainer._forward_backward(self.inputs)
+            ref_grad = flat.flat_grad.clone()
+            ref_td = ref.td_errors.clone()
+            torch.cuda.synchronize()
+            restore()
+            torch.cuda.set_rng_state(rng, tb.grid.device)
+            graph.replay()
+            torch.cuda.synchronize()
+            restore()
+            denom = float(torch.linalg.vector_norm(ref_grad)) + 1e-12
+            err = float(torch.linalg.vector_norm(flat.flat_grad - ref_grad)) / denom
+            err_td = float((self.outputs[4] - ref_td).abs().max()) / (float(ref_td.abs().max()) + 1e-12)
+            worst = max(worst, err, err_td)
+            if not (worst <= tol):  # also catches NaN
+                break
+        self.max_rel_err = worst
+        if worst <= tol:
+            self.graph = graph
+        else:
+            logger.warning("Learner HIP graph replay differs from the eager pass (rel err %.3g); staying eager.", worst)
+
+    @property
+    def ok(self) -> bool:
+        return self.graph is not None
+
+    def matches(self, tb: TensorBatch) -> bool:
+        return tuple(tb.grid.shape) == self.shape
+
+    def run(self, tb: TensorBatch) -> tuple[torch.Tensor, ...]:
+        assert self.graph is not None
+        i = self.inputs
+        i.grid.copy_(tb.grid)
+        i.other.copy_(tb.other)
+        i.policy_target.copy_(tb.policy_target)
+        i.returns.copy_(tb.returns)
+        i.weights.copy_(tb.weights)
+        self.graph.replay()
+        return tuple(o.clone() for o in self.outputs)  # the static outputs are overwritten by the next replay
+
+
 class Trainer:
     def __init__(
         self,
@@ -58,6 +166,7 @@ class Trainer:
         autocast_bf16: bool = False,
         grad_sync: Callable[[torch.Tensor], None] | None = None,
         world_size: int = 1,
+        use_graph: bool | None = None,
     ):
         self.nn = nn_interface
         self.model = nn_interface.model
@@ -78,6 +187,12 @@ class Trainer:
         self.v_max = self.model_config.VALUE_MAX
         self.delta_z = (self.v_max - self.v_min) / (self.num_atoms - 1)
         self.action_dim = int(env_config.NUM_SHAPE_SLOTS * env_config.ROWS * env_config.COLS)
+        # HIP-graph capture of forward+backward: needs the flat (static-address) gradient buffer
+        self.use_graph = bool(
+            use_graph if use_graph is not None else getattr(train_config, "COMPILE_MODEL", False)
+        ) and self.device.type == "cuda" and self.flat is not None
+        self._graphed: GraphedForwardBackward | None = None
+        self.graph_report: dict[str, Any] = {}  # outcome of the capture attempt (node census, validation error)
 
     # ------------------------------------------------------------------ construction
     def _create_optimizer(self, fused: bool) -> tuple[torch.optim.Optimizer, FlatParameterSpace | None]:
@@ -139,9 +254,8 @@ class Trainer:
         return c51_two_hot(n_step_returns, self.v_min, self.v_max, self.num_atoms)
 
     # ------------------------------------------------------------------ the step
-    def train_step_tensors(self, tb: TensorBatch) -> tuple[dict[str, torch.Tensor], torch.Tensor]:
-        """One step on device tensors; returns device scalars and ``td_errors [B]`` without host syncs."""
-        self.model.train()
+    def _forward_backward(self, tb: TensorBatch) -> LossOutputs:
+        """Zero the gradients, run forward + loss + backward; gradients end up in ``p.grad`` / the flat buffer."""
         self.optimizer.zero_grad()
         if self.autocast_bf16:
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
@@ -161,6 +275,43 @@ class Trainer:
             entropy_weight=self.train_config.ENTROPY_BONUS_WEIGHT,
         )
         out.total.backward()
+        return out
+
+    def _graph_for(self, tb: TensorBatch) -> GraphedForwardBackward | None:
+        """The validated graph for this batch shape, capturing it on first use; ``None`` means run eagerly."""
+        if not self.use_graph:
+            return None
+        if self._graphed is None:
+            if len(tb) != self.train_config.BATCH_SIZE:
+                return None  # capture only the steady-state batch shape
+            try:
+                self._graphed = GraphedForwardBackward(self, tb)
+            except Exception as exc:  # capture is an optimisation: any failure leaves the eager path
+                logger.warning("Learner HIP graph capture failed (%s); staying eager.", exc)
+                self.use_graph = False
+                return None
+            g = self._graphed
+            self.graph_report = {
+                "replayed": g.ok, "kernel_nodes": g.kernel_nodes, "memset_nodes": g.memset_nodes, "max_rel_err": g.max_rel_err,
+            }
+            if not g.ok:
+                self.use_graph = False
+                self._graphed = None
+                return None
+            logger.info("Learner forward/backward captured in a HIP graph (replay vs eager rel err %.2g).", self._graphed.max_rel_err)
+        return self._graphed if self._graphed.matches(tb) else None
+
+    def train_step_tensors(self, tb: TensorBatch) -> tuple[dict[str, torch.Tensor], torch.Tensor]:
+        """One step on device tensors; returns device scalars and ``td_errors [B]`` without host syncs."""
+        self.model.train()
+        graphed = self._graph_for(tb)
+        if graphed is not None:
+            total, policy_loss, value_loss, entropy, td_errors = graphed.run(tb)
+        else:
+            out = self._forward_backward(tb)
+            total, policy_loss, value_loss, entropy, td_errors = (
+                out.total.detach(), out.policy_loss, out.value_loss, out.entropy, out.td_errors,
+            )
         if self.grad_sync is not None and self.flat is not None:
             self.grad_sync(self.flat.flat_grad)
         clip = self.train_config.GRADIENT_CLIP_VALUE
@@ -170,13 +321,13 @@ class Trainer:
         if self.scheduler:
             self.scheduler.step()
         info = {
-            "total_loss": out.total.detach(),
-            "policy_loss": out.policy_loss,
-            "value_loss": out.value_loss,
-            "entropy": out.entropy,
-            "mean_td_error": out.td_errors.abs().mean(),
+            "total_loss": total,
+            "policy_loss": policy_loss,
+            "value_loss": value_loss,
+            "entropy": entropy,
+            "mean_td_error": td_errors.abs().mean(),
         }
-        return info, out.td_errors
+        return info, td_errors
 
     def train_step(self, per_sample: PERBatchSample | TensorBatch) -> tuple[dict[str, float], np.ndarray] | None:
         """Reference-shaped step: returns ``(loss_info floats, td_errors ndarray)`` or ``None`` on an empty batch."""

@@ -23,10 +23,11 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="no HIP-graph capture of forward/backward")
     args = ap.parse_args()
     dev = torch.device("cuda")
     env, mc = EnvConfig(), ModelConfig()
-    tc = TrainConfig(DEVICE="cuda", BATCH_SIZE=args.batch)
+    tc = TrainConfig(DEVICE="cuda", BATCH_SIZE=args.batch, COMPILE_MODEL=not args.eager)
     net = NeuralNetwork(mc, env, tc, dev)
     trainer = Trainer(net, tc, env, autocast_bf16=not args.fp32)
     replay = DeviceReplayBuffer(tc, env, mc, dev, SystemConfig())

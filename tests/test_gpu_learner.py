@@ -140,3 +140,68 @@ def test_trainer_step_on_device_batch_changes_params():
     net.sync_inference_weights()  # engine re-pack after training must still evaluate
     lg, v = net.evaluate_features(batch.grid, batch.other)
     assert torch.isfinite(lg).all() and torch.isfinite(v).all()
+
+
+@pytest.mark.parametrize("preset", ["cnn", "default"])
+def test_graphed_learner_step_matches_eager_trajectory(preset):
+    """COMPILE_MODEL: forward/backward replayed from a HIP graph when the graph passes its guards (no memset nodes,
+    replays reproduce eager gradients).  Two trainers from the same weights train on the same batches, one eager and
+    one asking for the graph, with eager work and synchronisation between the replays; their parameters have to stay
+    together whether the graph was accepted or refused, and a refusal has to come with its reason."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.rl.core.trainer import TensorBatch, Trainer
+
+    dev = torch.device("cuda")
+    env = EnvConfig()
+    mc = ModelConfig() if preset == "default" else ModelConfig(USE_TRANSFORMER=False)
+    trainers = []
+    for graph in (False, True):
+        torch.manual_seed(3)
+        tc = TrainConfig(DEVICE="cuda", BATCH_SIZE=64, MAX_TRAINING_STEPS=100, COMPILE_MODEL=graph)
+        net = NeuralNetwork(mc, env, tc, dev)
+        for m in net.model.modules():  # dropout off: the two trajectories then differ only by summation order
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if isinstance(m, torch.nn.MultiheadAttention):
+                m.dropout = 0.0
+        trainers.append(Trainer(net, tc, env, autocast_bf16=True))
+    eager, graphed = trainers
+    assert not eager.use_graph and graphed.use_graph
+    assert torch.equal(eager.flat.flat_param, graphed.flat.flat_param)
+    start = eager.flat.flat_param.clone()
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for step in range(8):
+        pol = torch.rand(64, env.ACTION_DIM, generator=gen)
+        tb = TensorBatch(
+            torch.randint(-1, 2, (64, mc.GRID_INPUT_CHANNELS, env.ROWS, env.COLS), generator=gen).float().to(dev),
+            torch.rand(64, mc.OTHER_NN_INPUT_FEATURES_DIM, generator=gen).to(dev),
+            (pol / pol.sum(1, keepdim=True)).to(dev),
+            torch.empty(64).uniform_(-5, 5, generator=gen).to(dev),
+            torch.rand(64, generator=gen).to(dev) + 0.5,
+        )
+        info_e, td_e = eager.train_step_tensors(tb)
+        torch.cuda.synchronize()
+        info_g, td_g = graphed.train_step_tensors(tb)
+        torch.cuda.synchronize()
+        assert abs(float(info_e["total_loss"]) - float(info_g["total_loss"])) < 2e-2 * abs(float(info_e["total_loss"])) + 1e-3
+        assert torch.allclose(td_e, td_g, rtol=5e-2, atol=5e-2)
+        assert torch.isfinite(graphed.flat.flat_grad).all() and torch.isfinite(graphed.flat.flat_param).all(), step
+    report = graphed.graph_report
+    print(f"learner graph [{preset}]: {report}")
+    assert report["kernel_nodes"] > 50
+    if report["replayed"]:
+        assert report["memset_nodes"] == 0 and report["max_rel_err"] < 2e-2 and graphed.use_graph
+    else:
+        assert report["memset_nodes"] > 0 or not report["max_rel_err"] < 2e-2
+        assert not graphed.use_graph
+    # AdamW normalises every coordinate's step to about lr, so compare against the distance travelled
+    apart = float(torch.linalg.vector_norm(eager.flat.flat_param - graphed.flat.flat_param))
+    travelled = float(torch.linalg.vector_norm(eager.flat.flat_param - start))
+    assert travelled > 0 and apart < 0.2 * travelled, (apart, travelled)
+    # BatchNorm running statistics advanced exactly once per step on both sides
+    for be, bg in zip(eager.model.buffers(), graphed.model.buffers(), strict=True):
+        assert torch.allclose(be.float(), bg.float(), rtol=1e-2, atol=1e-3)
+    # a batch of another size runs eagerly through the same trainer
+    small = TensorBatch(tb.grid[:32], tb.other[:32], tb.policy_target[:32], tb.returns[:32], tb.weights[:32])
+    info_s, td_s = graphed.train_step_tensors(small)
+    assert td_s.shape == (32,) and torch.isfinite(info_s["total_loss"])
