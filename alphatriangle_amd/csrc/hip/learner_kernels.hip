@@ -237,6 +237,50 @@ __global__ void per_priorities_kernel(double* tree, long long P, const int* idx,
   atomicMax(reinterpret_cast<unsigned int*>(max_prio), __float_as_uint(pr));  // positive floats order like uints
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Column sums of a row-major [N, F] matrix (bias gradients of the encoder's linear layers: N = tokens * batch).
+// Two plain stages - per-row-block partial sums, then their sum - with no atomics and no semaphores, so the op
+// records nothing but two kernel nodes when the learner step is captured into a HIP graph.
+template <typename T>
+__device__ __forceinline__ float colsum_load(const T* p);
+template <>
+__device__ __forceinline__ float colsum_load<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float colsum_load<unsigned short>(const unsigned short* p) { return bf16_to_float(*p); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ g, float* __restrict__ partial,
+                                                             int N, int F, int rows_per_block) {
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(N, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < F) {
+    int r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {
+      a0 += colsum_load(g + (size_t)r * F + col);
+      a1 += colsum_load(g + (size_t)(r + 4) * F + col);
+      a2 += colsum_load(g + (size_t)(r + 8) * F + col);
+      a3 += colsum_load(g + (size_t)(r + 12) * F + col);
+    }
+    for (; r < r1; r += 4) a0 += colsum_load(g + (size_t)r * F + col);
+  }
+  sm[wave][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave == 0 && col < F) partial[(size_t)blockIdx.y * F + col] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                           int blocks, int F) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= F) return;
+  float acc = 0.f;
+  for (int b = 0; b < blocks; ++b) acc += partial[(size_t)b * F + col];
+  out[col] = acc;
+}
+
 extern "C" {
 
 int atri_az_loss(const float* plog, const float* vlog, const float* ptgt, const float* ret, const float* isw,
@@ -297,6 +341,22 @@ int atri_per_priorities(double* tree, long long P, const int* idx, const float* 
   if (n <= 0) return 0;
   hipLaunchKernelGGL(per_priorities_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tree, P, idx, err, n, alpha, eps,
                      max_prio);
+  return (int)hipGetLastError();
+}
+
+// out[F] = column sums of g[N, F]; partial holds ceil(N / rows_per_block) * F floats.
+int atri_colsum(const void* g, int is_bf16, float* partial, float* out, int N, int F, int rows_per_block,
+                hipStream_t s) {
+  if (N <= 0 || F <= 0 || rows_per_block <= 0) return (int)hipErrorInvalidValue;
+  const int blocks = (N + rows_per_block - 1) / rows_per_block;
+  dim3 grid((F + 63) / 64, blocks);
+  if (is_bf16)
+    hipLaunchKernelGGL(colsum_partial_kernel<unsigned short>, grid, dim3(256), 0, s, (const unsigned short*)g, partial,
+                       N, F, rows_per_block);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)g, partial, N, F,
+                       rows_per_block);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 255) / 256), dim3(256), 0, s, partial, out, blocks, F);
   return (int)hipGetLastError();
 }
 

@@ -20,14 +20,84 @@ from ..config.env_config import EnvConfig
 from ..config.model_config import ModelConfig
 
 
+def _split_count(n: int, limit: int = 32, min_chunk: int = 512) -> int:
+    """Largest divisor of ``n`` that is at most ``limit`` and leaves chunks of at least ``min_chunk``."""
+    for s in range(min(limit, max(1, n // min_chunk)), 1, -1):
+        if n % s == 0:
+            return s
+    return 1
+
+
+def _patch_matrix(x: torch.Tensor, kh: int, kw: int, ph: int, pw: int) -> torch.Tensor:
+    """im2col for stride 1: ``[B, C, H, W]`` -> ``[C*kh*kw, B*oh*ow]`` (row order ``(c, kh, kw)``, column order ``(b, oh, ow)``).
+
+    ``F.unfold`` launches one im2col kernel PER SAMPLE (1536 launches per learner step at batch 256); strided views of
+    the padded input plus one gathering copy build the matrix in two launches.
+    """
+    b, c, h, w = x.shape
+    if kh == 1 and kw == 1 and ph == 0 and pw == 0:
+        return x.permute(1, 0, 2, 3).reshape(c, b * h * w)
+    xp = torch.nn.functional.pad(x, (pw, pw, ph, ph))
+    patches = xp.unfold(2, kh, 1).unfold(3, kw, 1)  # [B, C, oh, ow, kh, kw] (view)
+    oh, ow = patches.shape[2], patches.shape[3]
+    return patches.permute(1, 4, 5, 0, 2, 3).reshape(c * kh * kw, b * oh * ow)
+
+
+class _ConvGemm(torch.autograd.Function):
+    """Stride-1 convolution as ``W[Cout, K] @ patches[K, N]`` with all three GEMMs shaped for hipBLASLt.
+
+    ``N = batch * pixels`` (30 720 at batch 256), ``K = Cin*kh*kw`` (1152 for the residual convolutions).
+
+    * forward and data gradient are both "small matrix times patch matrix" products: the data gradient is the
+      convolution of the output gradient with the flipped, transposed filter, so it gathers patches of the output
+      gradient and reuses the forward GEMM shape.  (The transposed product ``W^T @ grad`` followed by a col2im
+      scatter measured 164 us + 2 x 42 us per residual convolution against 16 us + 25 us this way.)
+    * the weight gradient reduces over ``N`` into only ``Cout x K`` (9 tiles of 128 x 128): one plain GEMM keeps 9 of
+      256 compute units busy, so ``N`` is cut into up to 32 chunks that run as ONE strided batched GEMM over views
+      (no copies) and the partial products are added (164 us -> 28 us).
+    """
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, ph: int, pw: int) -> torch.Tensor:  # noqa: ANN001
+        b, _, h, w = x.shape
+        cout, _, kh, kw = weight.shape
+        cols = _patch_matrix(x, kh, kw, ph, pw)
+        ctx.save_for_backward(cols, weight)
+        ctx.geom = (b, h, w, ph, pw)
+        oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+        out = weight.reshape(cout, -1) @ cols  # [Cout, B*oh*ow]
+        return out.view(cout, b, oh, ow).permute(1, 0, 2, 3).contiguous()
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
+        cols, weight = ctx.saved_tensors
+        b, h, w, ph, pw = ctx.geom
+        cout, cin, kh, kw = weight.shape
+        d_x = d_w = None
+        if ctx.needs_input_grad[1]:
+            n = cols.shape[1]
+            k = cols.shape[0]
+            g2 = grad_out.permute(1, 0, 2, 3).reshape(cout, n)
+            s = _split_count(n)
+            parts = torch.bmm(g2.view(cout, s, n // s).transpose(0, 1), cols.view(k, s, n // s).permute(1, 2, 0))
+            d_w = (parts.sum(0) if s > 1 else parts[0]).view(cout, cin, kh, kw)
+        if ctx.needs_input_grad[0]:
+            g_cols = _patch_matrix(grad_out, kh, kw, kh - 1 - ph, kw - 1 - pw)  # [Cout*kh*kw, B*H*W]
+            w_t = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * kh * kw)
+            d_x = (w_t @ g_cols).view(cin, b, h, w).permute(1, 0, 2, 3).contiguous()
+        return d_x, d_w, None, None
+
+
 class GemmConv2d(nn.Conv2d):
     """``nn.Conv2d`` (same parameters, same ``state_dict`` keys) whose GPU path is im2col + GEMM.
 
     On gfx950 MIOpen has no tuned bf16 / fp32 convolution for these tiny 8x15 images and falls
     back to naive kernels (11 ms for one weight-gradient call at batch 256).  Lowering the
-    convolution to a patch matrix + one batched matmul puts forward, data-gradient and
-    weight-gradient on hipBLASLt GEMMs, which is what the learner needs.  CPU tensors keep the
-    stock implementation.
+    convolution to a patch matrix ``[Cin*kh*kw, batch*pixels]`` + one large GEMM (:class:`_ConvGemm`)
+    puts forward, data gradient and weight gradient on well-shaped hipBLASLt GEMMs, which is what
+    the learner needs.  CPU tensors keep the stock implementation.
     """
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -38,24 +108,107 @@ class GemmConv2d(nn.Conv2d):
             or self.groups != 1
             or isinstance(self.padding, str)
             or self.padding_mode != "zeros"
+            or self.kernel_size[0] - 1 < self.padding[0]
+            or self.kernel_size[1] - 1 < self.padding[1]
         ):
             return super().forward(x)
-        b, _, h, w = x.shape
-        kh, kw = self.kernel_size
-        ph, pw = self.padding
-        oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-        if kh == 1 and kw == 1 and ph == 0 and pw == 0:
-            cols = x.reshape(b, x.shape[1], h * w)
-        else:
-            # F.unfold launches one im2col kernel PER SAMPLE (1536 launches per step at batch 256); strided views of the
-            # padded input plus one gathering copy build the same [B, Cin*kh*kw, oh*ow] matrix in two launches
-            xp = torch.nn.functional.pad(x, (pw, pw, ph, ph))
-            patches = xp.unfold(2, kh, 1).unfold(3, kw, 1)  # [B, Cin, oh, ow, kh, kw] (view)
-            cols = patches.permute(0, 1, 4, 5, 2, 3).reshape(b, x.shape[1] * kh * kw, oh * ow)
-        out = torch.matmul(self.weight.reshape(self.out_channels, -1), cols)  # [B, Cout, oh*ow]
+        return self.gemm_forward(x)
+
+    def gemm_forward(self, x: torch.Tensor) -> torch.Tensor:
+        out = _ConvGemm.apply(x, self.weight, int(self.padding[0]), int(self.padding[1]))
         if self.bias is not None:
-            out = out + self.bias.view(1, -1, 1)
-        return out.view(b, self.out_channels, oh, ow)
+            out = out + self.bias.to(out.dtype).view(1, -1, 1, 1)
+        return out
+
+
+class _SplitKLinear(torch.autograd.Function):
+    """``y[N, out] = x[N, in] @ W[out, in]^T + b`` whose weight gradient is a split-K batched GEMM.
+
+    The encoder's linear layers see ``N = tokens * batch`` = 30 720 rows at batch 256 while their weight gradients
+    are at most 384 x 128: hipBLASLt runs that reduction on two to six workgroups (127 - 164 us per layer).  Cutting
+    the rows into up to 32 contiguous chunks turns it into one batched GEMM with enough tiles to fill the chip; the
+    bias gradient is a two-stage column sum (``ops.hip_learner.colsum``) without semaphores, so that a captured
+    learner step holds no memset nodes.
+    """
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    def forward(ctx, x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:  # noqa: ANN001
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x2, weight.t()) if bias is not None else x2 @ weight.t()
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
+        x2, weight = ctx.saved_tensors
+        g = grad_out.contiguous()
+        n, out_f = g.shape
+        s = _split_count(n)
+        gs = g.view(s, n // s, out_f)
+        d_x = g @ weight if ctx.needs_input_grad[0] else None
+        d_w = None
+        if ctx.needs_input_grad[1]:
+            d_w = torch.bmm(gs.transpose(1, 2), x2.reshape(s, n // s, x2.shape[1])).sum(0)
+        d_b = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if g.is_cuda and g.dtype in (torch.bfloat16, torch.float32):
+                from ..ops import hip_learner  # torch's multi-block column sum records a memset node under capture
+
+                d_b = hip_learner.colsum(g).to(g.dtype)
+            else:
+                d_b = gs.sum(1).sum(0)
+        return d_x, d_w, d_b
+
+
+def _linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """``F.linear`` over the flattened leading dimensions through :class:`_SplitKLinear`."""
+    lead = x.shape[:-1]
+    y = _SplitKLinear.apply(x.reshape(-1, x.shape[-1]), weight, bias)
+    return y.view(*lead, weight.shape[0])
+
+
+class EncoderLayer(nn.TransformerEncoderLayer):
+    """``nn.TransformerEncoderLayer`` (same sub-modules, same ``state_dict`` keys) with a learner fast path.
+
+    For the configuration the network uses (pre-LayerNorm, ``[tokens, batch, dim]`` input, no masks) the GPU forward
+    is written out here so that every linear layer goes through :class:`_SplitKLinear` and attention is two batched
+    GEMMs around a softmax; the arithmetic is that of the stock layer
+    (``x + drop(attn(norm1(x)))``, then ``x + drop(ffn(norm2(x)))``).  Everything else falls back to the stock
+    implementation.
+    """
+
+    def _fast_ok(self, src: torch.Tensor, src_mask, src_key_padding_mask, is_causal: bool) -> bool:  # noqa: ANN001
+        attn = self.self_attn
+        return (
+            src.is_cuda and src.dim() == 3 and self.norm_first and src_mask is None and src_key_padding_mask is None
+            and not is_causal and not attn.batch_first and attn._qkv_same_embed_dim and attn.in_proj_bias is not None
+            and attn.bias_k is None and not attn.add_zero_attn
+        )
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None, is_causal=False):  # noqa: ANN001
+        if not self._fast_ok(src, src_mask, src_key_padding_mask, is_causal):
+            return super().forward(src, src_mask=src_mask, src_key_padding_mask=src_key_padding_mask, is_causal=is_causal)
+        return self.fast_forward(src)
+
+    def fast_forward(self, src: torch.Tensor) -> torch.Tensor:
+        attn = self.self_attn
+        seq, batch, dim = src.shape
+        heads = attn.num_heads
+        y = self.norm1(src)
+        qkv = _linear_rows(y, attn.in_proj_weight, attn.in_proj_bias)  # [L, B, 3D]
+        q, k, v = (t.reshape(seq, batch, heads, dim // heads).permute(1, 2, 0, 3) for t in qkv.chunk(3, dim=-1))
+        # Written-out attention (two batched GEMMs around a softmax) instead of the flash kernel: with 120 tokens the
+        # score matrix is small, and the flash backward zero-fills its accumulators through memset nodes, which
+        # keeps the learner step out of a replayable HIP graph.
+        scores = (q * (dim // heads) ** -0.5) @ k.transpose(-2, -1)  # [B, H, L, L]
+        with torch.autocast(device_type=src.device.type, enabled=False):
+            probs = torch.softmax(scores, dim=-1)  # bf16 in / bf16 out under autocast, fp32 accumulation inside
+        probs = torch.nn.functional.dropout(probs, attn.dropout, self.training)
+        ctx = (probs @ v).permute(2, 0, 1, 3).reshape(seq, batch, dim)
+        x = src + self.dropout1(_linear_rows(ctx, attn.out_proj.weight, attn.out_proj.bias))
+        hidden = self.dropout(self.activation(_linear_rows(self.norm2(x), self.linear1.weight, self.linear1.bias)))
+        return x + self.dropout2(_linear_rows(hidden, self.linear2.weight, self.linear2.bias))
 
 
 def conv_block(
@@ -181,7 +334,7 @@ class AlphaTriangleNet(nn.Module):
             if channels != d:
                 self.input_proj = GemmConv2d(channels, d, kernel_size=1)
             self.pos_encoder = PositionalEncoding(d, dropout=0.1)
-            layer = nn.TransformerEncoderLayer(
+            layer = EncoderLayer(
                 d_model=d,
                 nhead=mc.TRANSFORMER_HEADS,
                 dim_feedforward=mc.TRANSFORMER_FC_DIM,

@@ -88,6 +88,20 @@ def flat_optimizer_step(*, kind: str, param: torch.Tensor, grad: torch.Tensor, m
     return norm_buf[0]
 
 
+def colsum(g: torch.Tensor) -> torch.Tensor:
+    """fp32 column sums of a contiguous ``[N, F]`` bf16 / fp32 matrix (two kernels, no atomics, graph-capturable)."""
+    if g.dim() != 2 or not g.is_contiguous() or g.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError(f"colsum needs a contiguous 2-D bf16/fp32 matrix, got {tuple(g.shape)} {g.dtype}")
+    n, f = g.shape
+    rows_per_block = 512 if n >= 8192 else 64
+    blocks = (n + rows_per_block - 1) // rows_per_block
+    partial = torch.empty(blocks * f, dtype=torch.float32, device=g.device)
+    out = torch.empty(f, dtype=torch.float32, device=g.device)
+    hb.call("atri_colsum", hb.ptr(g), hb.i32(1 if g.dtype == torch.bfloat16 else 0), hb.ptr(partial), hb.ptr(out),
+            hb.i32(n), hb.i32(f), hb.i32(rows_per_block))
+    return out
+
+
 # ---------------------------------------------------------------- prioritized replay tree
 def per_set_leaves(tree: torch.Tensor, P: int, idx: torch.Tensor, count: torch.Tensor | None, count_max: int, prio: torch.Tensor) -> None:
     hb.call("atri_per_set_leaves", hb.ptr(tree), hb.i64(P), hb.ptr(idx), hb.ptr(count), hb.i32(count_max), hb.ptr(prio))

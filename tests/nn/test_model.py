@@ -76,3 +76,48 @@ def test_gemm_conv_lowering_equals_conv2d():
     cols = torch.nn.functional.unfold(x, (3, 3), padding=(1, 1))
     lowered = (conv.weight.reshape(5, -1) @ cols + conv.bias.view(1, -1, 1)).view(2, 5, 8, 15)
     assert torch.allclose(lowered, conv(x), atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,k,p,bias", [(1, 8, 3, 1, False), (6, 10, 3, 1, True), (5, 7, 1, 0, True), (4, 6, 3, 0, False), (3, 5, 3, 2, True)])
+def test_gemm_conv_matches_conv2d_forward_and_gradients(cin, cout, k, p, bias):
+    """The learner's patch-matrix convolution (split-K weight gradient included) against ``F.conv2d`` in float64."""
+    import torch.nn.functional as F
+
+    from alphatriangle_amd.models.model import GemmConv2d, _split_count
+
+    assert _split_count(30720) == 32 and _split_count(7) == 1 and 1920 % _split_count(1920) == 0
+    torch.manual_seed(0)
+    conv = GemmConv2d(cin, cout, k, 1, p, bias=bias).double()
+    x = torch.randn(16, cin, 8, 15, dtype=torch.double, requires_grad=True)
+    params = [x, conv.weight] + ([conv.bias] if bias else [])
+    y_gemm = conv.gemm_forward(x)
+    y_ref = F.conv2d(x, conv.weight, conv.bias, 1, p)
+    assert y_gemm.shape == y_ref.shape and y_gemm.is_contiguous()
+    assert torch.allclose(y_gemm, y_ref, atol=1e-12)
+    g = torch.randn_like(y_ref)
+    for a, b in zip(torch.autograd.grad(y_gemm, params, g), torch.autograd.grad(y_ref, params, g), strict=True):
+        assert torch.allclose(a, b, atol=1e-10)
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu"])
+def test_encoder_layer_fast_path_matches_stock_layer(act):
+    """The written-out pre-LN layer (split-K linear layers, 2048 rows -> 4 chunks) against ``nn.TransformerEncoderLayer``."""
+    from alphatriangle_amd.models.model import EncoderLayer, _split_count
+
+    assert _split_count(64 * 32) == 4
+    torch.manual_seed(0)
+    layer = EncoderLayer(d_model=32, nhead=4, dim_feedforward=64, activation=act, batch_first=False, norm_first=True).double()
+    layer.eval()  # dropout off: the two paths draw their masks differently
+    x = torch.randn(64, 32, 32, dtype=torch.double, requires_grad=True)
+    y_fast = layer.fast_forward(x)
+    y_ref = torch.nn.TransformerEncoderLayer.forward(layer, x)
+    assert torch.allclose(y_fast, y_ref, atol=1e-10)
+    g = torch.randn_like(y_ref)
+    params = [x] + list(layer.parameters())
+    for a, b in zip(torch.autograd.grad(y_fast, params, g), torch.autograd.grad(y_ref, params, g), strict=True):
+        assert torch.allclose(a, b, atol=1e-9)
+    # state_dict keys are those of the stock layer (checkpoints stay interchangeable)
+    stock = torch.nn.TransformerEncoderLayer(d_model=32, nhead=4, dim_feedforward=64, activation=act, norm_first=True)
+    assert list(stock.state_dict().keys()) == list(layer.state_dict().keys())
+    # CPU tensors and masked calls use the stock implementation
+    assert not layer._fast_ok(x, None, None, False)

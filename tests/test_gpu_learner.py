@@ -205,3 +205,15 @@ def test_graphed_learner_step_matches_eager_trajectory(preset):
     small = TensorBatch(tb.grid[:32], tb.other[:32], tb.policy_target[:32], tb.returns[:32], tb.weights[:32])
     info_s, td_s = graphed.train_step_tensors(small)
     assert td_s.shape == (32,) and torch.isfinite(info_s["total_loss"])
+
+
+@pytest.mark.parametrize("n,f,dtype", [(30720, 384, torch.bfloat16), (30720, 128, torch.float32), (1000, 72, torch.bfloat16), (7, 5, torch.float32)])
+def test_colsum_kernel_matches_fp32_sum(n, f, dtype):
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(n + f)
+    g = torch.randn(n, f, device="cuda").to(dtype)
+    ref = g.float().sum(0)
+    out = hip_learner.colsum(g)
+    assert out.dtype == torch.float32 and out.shape == (f,)
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-3 * (n ** 0.5))
