@@ -185,6 +185,25 @@ class DistContext:
         dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op], group=self.world_group)
         return float(t.item())
 
+    def warm_up(self) -> None:
+        """One tiny all-reduce on every group this rank belongs to (world, learners, cohort), in that order.
+
+        RCCL builds a communicator's channels (device allocations, IPC handles) on its first collective; doing that
+        here keeps it out of the HIP-graph captures of the first self-play move and the first learner step, during
+        which such calls are not permitted.  Every rank has to call this.
+        """
+        for grp, member in (
+            (self.world_group, True),
+            (self.learner_group, self.learner_group is not None and self.is_learner),
+            (self.cohort_group, self.cohort_group is not None),
+        ):
+            if not member or (grp is None and grp is not self.world_group):
+                continue
+            t = torch.zeros(1, dtype=torch.float32, device="cpu" if self._host_staged() else self.device)
+            dist.all_reduce(t, group=grp)
+        if not self._host_staged():
+            torch.cuda.synchronize(self.device)
+
     def barrier(self) -> None:
         if self._host_staged():
             dist.barrier(group=self.world_group)

@@ -137,6 +137,8 @@ def setup_training_components(
                 worker.nn_evaluator = neural_net  # published weights land in this rank's network
                 experience_source = HostExperienceSource(worker, layout, env_config.ACTION_DIM)
 
+        if dist_context is not None and dist_context.world_size > 1:
+            dist_context.warm_up()  # communicator set-up must not fall into the first graph captures
         trainer = None
         if not pure_actor:
             n_sync = 1

@@ -24,6 +24,7 @@ from alphatriangle_amd.rl.core.trainer import TensorBatch, Trainer
 ctx = init_distributed(0, 1, 0, backend="nccl", init_method="env://", timeout_s=60)
 assert ctx.backend == "nccl" and ctx.device.type == "cuda"
 dev = ctx.device
+ctx.warm_up()
 print("init ok", flush=True)
 
 x = torch.arange(1 << 20, dtype=torch.float32, device=dev)
