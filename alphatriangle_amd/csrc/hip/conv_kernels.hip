@@ -33,6 +33,9 @@ struct RowConvArgs {
   const float* w_first;  // [9][Cin] f32 (BatchNorm folded)
   const float* b_first;  // [Cin]
   int first_act, aux_off;
+  // PAIR instantiation only: second convolution of a residual block (same geometry, Cin = Cout = 128)
+  const unsigned short* w2;
+  const float* bias2;
 };
 
 namespace {
@@ -50,7 +53,12 @@ __device__ __noinline__ float4v act8_slow_rc(float4v v, int act) {
 // 2 no weight-fragment loads, 4 no main loop, 16 no input staging loads, 32 no write-back phase.
 // FIRST: the input tile is not read from memory but computed from the raw board (first conv layer, Cin_first = 1),
 // which removes a separate memory-bound kernel and the round trip of its output.
-template <int CIN, int DBG, bool FIRST = false>
+// PAIR: a whole residual block (alphatriangle/nn/model.py:40-59) per launch.  The first convolution's activated
+// output goes from the accumulators straight back into the halo tile (its lanes hold (pixel, 8 channels) chunks,
+// which is the tile's row layout; the halo stays zero), the second convolution runs from there and takes the skip
+// connection from the block input in memory.  Saves the write-back phase of one convolution, the staging phase
+// of the other and a kernel boundary per block.
+template <int CIN, int DBG, bool FIRST = false, bool PAIR = false>
 __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,6 +143,10 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
     const int ch_wave = nb * 128 + wave * 32;
     const bool active = ch_wave < a.Cout;  // wave-uniform
     float4v acc[8][2];
+#pragma unroll 1
+    for (int stage = 0; stage < (PAIR ? 2 : 1); ++stage) {
+    const unsigned short* wsrc = (PAIR && stage == 1) ? a.w2 : a.w;
+    const float* bsrc = (PAIR && stage == 1) ? a.bias2 : a.bias;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
       // runs, the four LDS fragments of the next half are in flight, and the two weight fragments of the
       // next step are requested a full step ahead.  sched_barrier(0) fences keep the compiler from sinking
       // those loads down to their first use (which would serialise every load with the MFMA that needs it).
-      const short8* wp = reinterpret_cast<const short8*>(a.w) + ((size_t)nb * STEPS * 4 + wave) * 128 + lane;
+      const short8* wp = reinterpret_cast<const short8*>(wsrc) + ((size_t)nb * STEPS * 4 + wave) * 128 + lane;
       short8 wb[2][2], av[2][4];
       wb[0][0] = wp[0];
       wb[0][1] = wp[64];
@@ -176,10 +188,41 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // every wave is done reading the input tile (the output tile may alias it)
+    float bias[8];
     if (active) {
-      float bias[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bias[i] = a.bias[ch_wave + q4 * 8 + i];
+      for (int i = 0; i < 8; ++i) bias[i] = bsrc[ch_wave + q4 * 8 + i];
+    }
+    if (PAIR && stage == 0) {
+      // first convolution of the block: bias + activation, back into the halo tile as the second one's input
+      if (active && l15 < W) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t >= H) continue;
+          float4v lo = acc[t][0], hi = acc[t][1];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            lo[j] += bias[j];
+            hi[j] += bias[4 + j];
+          }
+          if (a.act == kActReLU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              lo[j] = fmaxf(lo[j], 0.f);
+              hi[j] = fmaxf(hi[j], 0.f);
+            }
+          } else if (a.act != kActNone) {
+            lo = act8_slow_rc(lo, a.act);
+            hi = act8_slow_rc(hi, a.act);
+          }
+          *reinterpret_cast<short8*>(smem + (17 + t * 16 + l15) * stride + wave * 64 + q4 * 16) =
+              pack_bf16x8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    if (active) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         *reinterpret_cast<short8*>(otile + (t * 16 + l15) * kOutStride + wave * 64 + q4 * 16) =
@@ -188,6 +231,7 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
       }
     }
     __syncthreads();
+    }  // stage
 
     // ---- coalesced write-back: thread -> (pixel, 8-channel chunk), whole rows per wave ----
     const int n_ch = min(128, a.Cout - nb * 128);
@@ -257,14 +301,14 @@ int atri_rowconv_supported(int H, int W, int Cin, int Cout) {
 }  // extern "C"
 
 namespace {
-template <int CIN, int DBG, bool FIRST>
+template <int CIN, int DBG, bool FIRST, bool PAIR = false>
 int launch_rowconv_inst(const RowConvArgs& a, int lds, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)rowconv_kernel<CIN, DBG, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)rowconv_kernel<CIN, DBG, FIRST, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((rowconv_kernel<CIN, DBG, FIRST>), dim3(a.B), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((rowconv_kernel<CIN, DBG, FIRST, PAIR>), dim3(a.B), dim3(256), lds, stream, a);
   return hip_err(hipGetLastError());
 }
 
@@ -365,6 +409,41 @@ int atri_rowconv_first(const float* grid, const float* w_first, const float* b_f
   if (Cin == 32) return launch_rowconv_inst<32, 0, true>(a, lds, stream);
   if (Cin == 64) return launch_rowconv_inst<64, 0, true>(a, lds, stream);
   return launch_rowconv_inst<128, 0, true>(a, lds, stream);
+}
+
+// Residual block in one launch: out = act(conv2(act(conv1(in))) + in) (+ post_add), 128 channels throughout.
+// (w1, b1) / (w2, b2) are the two folded convolutions; the skip connection is read from `in`.
+int atri_rowconv_pair(const void* in, const void* w1, const float* b1, const void* w2, const float* b2,
+                      const float* post_add, void* out, int B, int H, int W, int C, int act, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (C != 128 || !atri_rowconv_supported(H, W, C, C)) return -10;
+  if (in == out) return -13;  // the skip connection is read after other workgroups may have written their output
+  RowConvArgs a{};
+  a.in = (const unsigned short*)in;
+  a.w = (const unsigned short*)w1;
+  a.bias = b1;
+  a.w2 = (const unsigned short*)w2;
+  a.bias2 = b2;
+  a.residual = (const unsigned short*)in;
+  a.post_add = post_add;
+  a.out = (unsigned short*)out;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.HW = H * W;
+  a.Cin = C;
+  a.Cout = C;
+  a.act = act;
+  a.n_blocks = 1;
+  a.log2_cpr = 4;  // 16 chunks of 8 channels per pixel
+  const int in_bytes = kInRows * (C * 2 + 32);
+  const int out_bytes = 128 * kOutStride;
+  a.out_off = 0;
+  const int lds = in_bytes > out_bytes ? in_bytes : out_bytes;
+  a.ymagic = 65536 / W + 1;
+  for (int p = 0; p < a.HW; ++p)
+    if (((p * a.ymagic) >> 16) != p / W) return -12;
+  return launch_rowconv_inst<128, 0, false, true>(a, lds, stream);
 }
 
 // Roofline probe: the same launch with ingredients removed (see the kernel's DBG parameter).

@@ -10,6 +10,7 @@ is the reference's (alphatriangle/nn/model.py:109-297).
 Layer -> kernel map (default config, B leaves, HW = 120 tokens):
   conv stem layer 0 (Cin = 1)            evaluated inside the staging of layer 1's rowconv_kernel (boards up to 8x15),
                                          else conv_first_kernel (VALU, memory bound)
+  residual blocks (128 channels)         rowconv_kernel<PAIR>: both convolutions in one launch, intermediate in LDS
   conv stem 1.., residual convs          rowconv_kernel (boards up to 8x15: halo tile in LDS, one sample per
                                          workgroup, coalesced write-back) else tile_gemm_kernel taps=9
   1x1 projections, QKV, out-proj, FFN    tile_gemm_kernel taps=1  (+LayerNorm prologue,
@@ -224,6 +225,7 @@ class InferenceEngine:
             and self.HW <= 256 and self.HW % 4 == 0
         )
         self.use_rowconv = True  # tests flip this to cover the generic tile kernel on small boards
+        self.fuse_res_blocks = True  # tests flip this to compare the fused residual-block kernel with two launches
         self._store: list[torch.Tensor] = []
         self._store_cursor = 0
 
@@ -417,6 +419,14 @@ class InferenceEngine:
             hb.i32(out_stride if out_stride is not None else layer.cout), hb.i32(layer.n_blocks), hb.f32(layer.ln_eps),
         )
 
+    def _pair_ok(self, l1: _GemmLayer, l2: _GemmLayer) -> bool:
+        """Both convolutions of a residual block fit the fused block kernel (8x15 boards, 128 channels, same activation)."""
+        return (
+            self.use_rowconv and self.fuse_res_blocks and self.H <= 8 and self.W <= 15
+            and l1.taps == 9 and l2.taps == 9 and l1.cin == l1.cout == l2.cin == l2.cout == 128
+            and l1.act == l2.act and l1.post_add is None and l1.ln_g is None and l2.ln_g is None
+        )
+
     @torch.no_grad()
     def forward(self, grid: torch.Tensor, other: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """``grid`` f32 [B, 1, H, W] (or [B, HW]), ``other`` f32 [B, Do] -> ``(logits [B, A], value [B])``.
@@ -454,7 +464,21 @@ class InferenceEngine:
         else:
             hb.call("atri_conv_first", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.ptr(bufs[0]),
                     hb.i32(rows), hb.i32(self.HW), hb.i32(self.H), hb.i32(self.W), hb.i32(self.c0), hb.i32(self.act))
-        for kind, layer in body:
+        skip_next = False
+        for li, (kind, layer) in enumerate(body):
+            if skip_next:
+                skip_next = False
+                continue
+            if kind == "res_a" and self._pair_ok(layer, body[li + 1][1]):
+                # whole residual block in one launch (the intermediate activation never leaves LDS)
+                l2 = body[li + 1][1]
+                dst = (cur + 1) % 3
+                hb.call("atri_rowconv_pair", hb.ptr(bufs[cur]), hb.ptr(layer.w), hb.ptr(layer.bias), hb.ptr(l2.w), hb.ptr(l2.bias),
+                        hb.ptr(l2.post_add), hb.ptr(bufs[dst]), hb.i32(B), hb.i32(self.H), hb.i32(self.W), hb.i32(layer.cin),
+                        hb.i32(layer.act))
+                cur = dst
+                skip_next = True
+                continue
             if kind in ("plain", "res_a"):
                 dst = (cur + 1) % 3
                 self._run_gemm(layer, bufs[cur], bufs[dst], rows, conv=True)

@@ -296,6 +296,49 @@ def test_rowconv_and_tile_gemm_paths_agree():
     assert (v1 - v2).abs().max().item() < 0.1
 
 
+@pytest.mark.parametrize("act,rows,cols", [("ReLU", 8, 15), ("GELU", 8, 15), ("ReLU", 6, 11)])
+def test_fused_residual_block_matches_two_launches_and_torch(act, rows, cols):
+    """rowconv_kernel<PAIR> (a residual block per launch) against the two-launch path (bit-level: same arithmetic
+    apart from the in-LDS intermediate) and against the fp32 PyTorch module."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(11)
+    dev = _dev()
+    env = EnvConfig(ROWS=rows, COLS=cols, PLAYABLE_RANGE_PER_ROW=[(0, cols)] * rows)
+    mc = ModelConfig(ACTIVATION_FUNCTION=act)
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev)
+    with torch.no_grad():  # non-trivial BatchNorm statistics so the folded biases matter
+        for m in net.model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    net.sync_inference_weights()
+    eng = net.engine
+    assert eng is not None and eng.fuse_res_blocks
+    res_a = [l for k, l in eng.body_layers if k == "res_a"][0]
+    res_b = [l for k, l in eng.body_layers if k == "res_b"][0]
+    assert eng._pair_ok(res_a, res_b)
+    B = 37
+    grid = torch.randint(-1, 2, (B, 1, rows, cols), device=dev).float()
+    other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    l1, v1 = (t.clone() for t in eng.forward(grid, other))
+    eng.fuse_res_blocks = False
+    try:
+        l2, v2 = (t.clone() for t in eng.forward(grid, other))
+    finally:
+        eng.fuse_res_blocks = True
+    torch.cuda.synchronize()
+    assert (l1 - l2).abs().max().item() < 0.03, (l1 - l2).abs().max().item()
+    assert (v1 - v2).abs().max().item() < 0.05
+    net.model.eval()
+    with torch.no_grad():
+        pl, vl = net.model(grid, other)
+    ref_v = (torch.softmax(vl.float(), 1) * net.support.to(dev)).sum(1)
+    assert (l1[:, : pl.shape[1]] - pl).abs().max().item() < 0.15
+    assert (v1 - ref_v).abs().max().item() < 0.25
+
+
 @pytest.mark.parametrize("hw", [252, 120, 64])
 def test_rows_attention_path_matches_torch(hw):
     """qkv_rows + attn_core + proj_rows (+ ffn_block) vs nn.TransformerEncoderLayer(norm_first=True) in fp32."""
