@@ -274,11 +274,24 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                            int blocks, int F) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= F) return;
-  float acc = 0.f;
-  for (int b = 0; b < blocks; ++b) acc += partial[(size_t)b * F + col];
-  out[col] = acc;
+  // 64 columns per workgroup; the four waves split the partial rows, four loads in flight per lane
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < F) {
+    int b = wave;
+    for (; b + 12 < blocks; b += 16) {
+      a0 += partial[(size_t)b * F + col];
+      a1 += partial[(size_t)(b + 4) * F + col];
+      a2 += partial[(size_t)(b + 8) * F + col];
+      a3 += partial[(size_t)(b + 12) * F + col];
+    }
+    for (; b < blocks; b += 4) a0 += partial[(size_t)b * F + col];
+  }
+  sm[wave][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave == 0 && col < F) out[col] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
 extern "C" {
@@ -356,7 +369,7 @@ int atri_colsum(const void* g, int is_bf16, float* partial, float* out, int N, i
   else
     hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)g, partial, N, F,
                        rows_per_block);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 255) / 256), dim3(256), 0, s, partial, out, blocks, F);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 63) / 64), dim3(256), 0, s, partial, out, blocks, F);
   return (int)hipGetLastError();
 }
 
