@@ -22,8 +22,9 @@ Layer -> kernel map (default config, B leaves, HW = 120 tokens):
   final LayerNorm + flatten + shared FC  fc_rows_splitk_kernel (128-channel bodies: LN applied while staging the
   (K = 15390)                            rows, no flattened copy) + fc_finish_kernel; else rows_to_fc_kernel +
                                          fc_splitk_kernel
-  policy / value heads                   tile_gemm_kernel taps=1 (rows = samples)
-  C51 expectation                        c51_expect_kernel
+  FC reduction, policy / value heads,    heads_kernel (head_kernels.hip: 128-wide hidden layers, 16 samples per
+  C51 expectation                        workgroup, one launch) else fc_finish_kernel + tile_gemm_kernel taps=1
+                                         (rows = samples) + c51_expect_kernel
 """
 
 from __future__ import annotations
@@ -226,6 +227,8 @@ class InferenceEngine:
         )
         self.use_rowconv = True  # tests flip this to cover the generic tile kernel on small boards
         self.fuse_res_blocks = True  # tests flip this to compare the fused residual-block kernel with two launches
+        self.use_fused_heads = True  # tests flip this to compare the fused tail kernel with the per-layer launches
+        self.heads_fused = False
         self._store: list[torch.Tensor] = []
         self._store_cursor = 0
 
@@ -367,6 +370,15 @@ class InferenceEngine:
         if self.fc_fused:
             self.fc_steps_per_split = ((total_steps + self.fc_sk - 1) // self.fc_sk + 3) // 4 * 4
             self.fc_sk = (total_steps + self.fc_steps_per_split - 1) // self.fc_steps_per_split
+        # default-shaped tail (128-wide shared / policy / value hidden layers): one fused kernel
+        pl, vl = self.policy_layers, self.value_layers
+        self.heads_fused = (
+            self.fc_n == 128 and not self.shared_rest and len(pl) == 2 and len(vl) == 2
+            and all(l.cin == 128 and l.taps == 1 and l.ln_g is None and l.post_add is None for l in pl + vl)
+            and pl[0].cout == 128 and vl[0].cout == 128 and pl[0].act == self.act and vl[0].act == self.act
+            and pl[1].act == 0 and vl[1].act == 0 and vl[1].cout <= 128 and pl[1].cout <= self.logit_stride
+            and vl[1].cout <= self.value_stride
+        )
         self.loaded = True
 
     # ------------------------------------------------------------------ buffers
@@ -542,6 +554,17 @@ class InferenceEngine:
                     hb.i32(self.other_pad), hb.i32(self.fc_kp), hb.i32(self.HW * self.feat_c))
             hb.call("atri_fc_splitk", hb.ptr(self.fc_in), hb.ptr(self.fc_w), hb.ptr(self.slabs), hb.i32(B), hb.i32(self.fc_kp),
                     hb.i32(self.fc_n), hb.i32(self.fc_sk))
+        if self.heads_fused and self.use_fused_heads:
+            # split-K reduction, both heads and the C51 expectation in one launch (csrc/hip/head_kernels.hip)
+            p1, p2 = self.policy_layers
+            v1, v2 = self.value_layers
+            dz = (self.mc.VALUE_MAX - self.mc.VALUE_MIN) / (self.mc.NUM_VALUE_ATOMS - 1)
+            hb.call("atri_heads", hb.ptr(self.slabs), hb.i32(self.fc_sk), hb.ptr(self.fc_b), hb.ptr(p1.w), hb.ptr(p1.bias),
+                    hb.ptr(p2.w), hb.ptr(p2.bias), hb.i32(p2.n_blocks), hb.i32(p2.cout), hb.ptr(v1.w), hb.ptr(v1.bias),
+                    hb.ptr(v2.w), hb.ptr(v2.bias), hb.i32(self.mc.NUM_VALUE_ATOMS), hb.i32(v2.cout), hb.ptr(self.logits),
+                    hb.i32(self.logit_stride), hb.ptr(self.vlogits), hb.i32(self.value_stride), hb.ptr(self.values),
+                    hb.f32(self.mc.VALUE_MIN), hb.f32(dz), hb.i32(B), hb.i32(self.act))
+            return self.logits[:B, : self.A], self.values[:B]
         # slabs are laid out [SK][cap][128]; the kernel indexes them with the live batch size
         hb.call("atri_fc_finish", hb.ptr(self.slabs), hb.ptr(self.fc_b), hb.ptr(self.dense[0]), hb.i32(B), hb.i32(self.fc_n),
                 hb.i32(self.fc_sk), hb.i32(self.act))

@@ -339,6 +339,48 @@ def test_fused_residual_block_matches_two_launches_and_torch(act, rows, cols):
     assert (v1 - ref_v).abs().max().item() < 0.25
 
 
+@pytest.mark.parametrize("act,batch", [("ReLU", 37), ("GELU", 16), ("ReLU", 1)])
+def test_fused_heads_kernel_matches_per_layer_launches(act, batch):
+    """heads_kernel (FC reduction + both heads + C51 expectation in one launch) against fc_finish + four tile GEMMs +
+    c51_expect on the same packed weights, including batch sizes that leave a partly filled 16-sample tile."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(12)
+    dev = _dev()
+    env, mc = EnvConfig(), ModelConfig(ACTIVATION_FUNCTION=act)
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev)
+    with torch.no_grad():
+        for m in net.model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    net.sync_inference_weights()
+    eng = net.engine
+    assert eng is not None and eng.heads_fused and eng.use_fused_heads
+    grid = torch.randint(-1, 2, (batch, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(batch, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    l1, v1 = (t.clone() for t in eng.forward(grid, other))
+    vl1 = eng.vlogits[:batch, : mc.NUM_VALUE_ATOMS].clone()
+    eng.use_fused_heads = False
+    try:
+        l2, v2 = (t.clone() for t in eng.forward(grid, other))
+        vl2 = eng.vlogits[:batch, : mc.NUM_VALUE_ATOMS].clone()
+    finally:
+        eng.use_fused_heads = True
+    torch.cuda.synchronize()
+    # same bf16 operands and fp32 accumulation in both paths: differences are summation order only
+    assert (l1 - l2).abs().max().item() < 2e-3, (l1 - l2).abs().max().item()
+    assert (vl1 - vl2).abs().max().item() < 2e-3
+    assert (v1 - v2).abs().max().item() < 2e-3
+    net.model.eval()
+    with torch.no_grad():
+        pl, vl = net.model(grid, other)
+    ref_v = (torch.softmax(vl.float(), 1) * net.support.to(dev)).sum(1)
+    assert (l1 - pl).abs().max().item() < 0.15
+    assert (v1 - ref_v).abs().max().item() < 0.25
+
+
 @pytest.mark.parametrize("hw", [252, 120, 64])
 def test_rows_attention_path_matches_torch(hw):
     """qkv_rows + attn_core + proj_rows (+ ffn_block) vs nn.TransformerEncoderLayer(norm_first=True) in fp32."""
