@@ -360,32 +360,37 @@ struct FfnBlockArgs {
 constexpr int kFfnTiles = 4;
 constexpr int kFfnRows = kFfnTiles * 16;
 constexpr int kFfnTileBytes = kFfnRows * kStride;
+constexpr int kFfnBlockTiles = 8;  // M-tiles per workgroup of ffn_block_kernel
 
-template <int HALVES>
-__global__ __launch_bounds__(256, 3) void ffn_block_kernel(FfnBlockArgs a) {
+// TILES = M-tiles (16 rows each) per workgroup: 4 -> three workgroups per CU, 8 -> two workgroups per CU that read
+// each weight fragment half as often (the weights of a workgroup are 128 KB from L2 against 16 KB of rows per 64 rows).
+template <int HALVES, int TILES>
+__global__ __launch_bounds__(256, (TILES <= 4 ? 3 : 2)) void ffn_block_kernel(FfnBlockArgs a) {
+  constexpr int kRowsWg = TILES * 16;
+  constexpr int kTileWg = kRowsWg * kStride;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* yn = smem;
-  unsigned char* hh = smem + kFfnTileBytes;
+  unsigned char* hh = smem + kTileWg;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
-  const int row0 = blockIdx.x * kFfnRows;
-  const int nrows = min(kFfnRows, a.rows - row0);
+  const int row0 = blockIdx.x * kRowsWg;
+  const int nrows = min(kRowsWg, a.rows - row0);
   const unsigned short* yg = a.y + (size_t)row0 * kD;
 
   const short8* w1p = reinterpret_cast<const short8*>(a.w1) + (size_t)wave * 128 + lane;
   const short8* w2p = reinterpret_cast<const short8*>(a.w2) + (size_t)wave * 128 + lane;
   WFrags wa, wb;
   load_wfrags(wa, w1p);  // first W1 block: in flight during staging and LayerNorm
-  {  // stage 64 rows x 16 chunks (rows beyond the end zeroed), loads issued before writes
-    uint4 v[4];
+  {  // stage the rows as 16-byte chunks (rows beyond the end zeroed), loads issued before writes
+    uint4 v[TILES];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TILES; ++i) {
       const int c = tid + i * 256;
       v[i] = make_uint4(0, 0, 0, 0);
       if (c < nrows * 16) v[i] = *reinterpret_cast<const uint4*>(yg + (size_t)c * 8);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TILES; ++i) {
       const int c = tid + i * 256;
       *reinterpret_cast<uint4*>(yn + (c >> 4) * kStride + (c & 15) * 16) = v[i];
     }
@@ -395,37 +400,37 @@ __global__ __launch_bounds__(256, 3) void ffn_block_kernel(FfnBlockArgs a) {
   __syncthreads();
 
   const int ch0 = wave * 32 + q4 * 8;
-  float4v acc_o[kFfnTiles][2];
+  float4v acc_o[TILES][2];
   {  // output bias preloaded into the accumulators
     float b2v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) b2v[i] = a.b2[ch0 + i];
 #pragma unroll
-    for (int t = 0; t < kFfnTiles; ++t) {
+    for (int t = 0; t < TILES; ++t) {
       acc_o[t][0] = (float4v){b2v[0], b2v[1], b2v[2], b2v[3]};
       acc_o[t][1] = (float4v){b2v[4], b2v[5], b2v[6], b2v[7]};
     }
   }
   constexpr int halves = HALVES;
-  ResFragsT<kFfnTiles> res;
+  ResFragsT<TILES> res;
 #pragma unroll
   for (int h = 0; h < halves; ++h) {
     {
       float bias[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) bias[i] = a.b1[h * 128 + ch0 + i];
-      float4v acc_h[kFfnTiles][2];
+      float4v acc_h[TILES][2];
 #pragma unroll
-      for (int t = 0; t < kFfnTiles; ++t) {
+      for (int t = 0; t < TILES; ++t) {
         acc_h[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
         acc_h[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
       }
       load_wfrags(wb, w2p + (size_t)h * 4 * 512);  // this half's W2 steps fly during the first GEMM
-      gemm_k128<false, kFfnTiles>(acc_h, wa, yn, l15, q4);
+      gemm_k128<false, TILES>(acc_h, wa, yn, l15, q4);
       if (h + 1 < halves) load_wfrags(wa, w1p + (size_t)(h + 1) * 4 * 512);  // next W1 block flies during the second GEMM
       if (h > 0) __syncthreads();  // the previous half's second GEMM has finished reading the hidden tile
 #pragma unroll
-      for (int t = 0; t < kFfnTiles; ++t) {
+      for (int t = 0; t < TILES; ++t) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -445,12 +450,12 @@ __global__ __launch_bounds__(256, 3) void ffn_block_kernel(FfnBlockArgs a) {
     }
     __syncthreads();
     if (h + 1 == halves) load_residual(res, yg + ch0, nrows, l15);
-    gemm_k128<false, kFfnTiles>(acc_o, wb, hh, l15, q4);
+    gemm_k128<false, TILES>(acc_o, wb, hh, l15, q4);
   }
 
   unsigned short* og = a.out + (size_t)row0 * kD;
 #pragma unroll
-  for (int t = 0; t < kFfnTiles; ++t) {
+  for (int t = 0; t < TILES; ++t) {
     int r = t * 16 + l15;
     asm volatile("" : "+v"(r));
     if (r >= nrows) continue;
@@ -476,14 +481,15 @@ int launch_attn(const AttnBlockArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <int HALVES>
+template <int HALVES, int TILES = kFfnBlockTiles>
 int launch_ffn(const FfnBlockArgs& a, hipStream_t stream) {
+  constexpr int rows_wg = TILES * 16, lds = 2 * rows_wg * kStride;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)ffn_block_kernel<HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFfnTileBytes);
+    (void)hipFuncSetAttribute((const void*)ffn_block_kernel<HALVES, TILES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
-  hipLaunchKernelGGL(ffn_block_kernel<HALVES>, dim3((a.rows + kFfnRows - 1) / kFfnRows), dim3(256), 2 * kFfnTileBytes, stream, a);
+  hipLaunchKernelGGL((ffn_block_kernel<HALVES, TILES>), dim3((a.rows + rows_wg - 1) / rows_wg), dim3(256), lds, stream, a);
   return (int)hipGetLastError();
 }
 }  // namespace
