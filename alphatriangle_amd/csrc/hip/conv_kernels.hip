@@ -133,11 +133,10 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
   }
   __syncthreads();
 
-  // LDS byte offset (relative to lane_base) of the fragment of image row t at GEMM step st = tap*KC + kc.
-  // Compile-time after unrolling: every ds_read of the main loop uses an immediate offset.
+  // Fragment addresses are lane_base + a compile-time offset after unrolling: every ds_read of the main loop
+  // uses an immediate offset.
   const unsigned char* lane_base = smem + l15 * stride + q4 * 16;
   unsigned char* otile = smem + a.out_off;
-#define ROWCONV_OFF(st, t) ((17 + (((st) / KC) / 3 - 1) * 16 + (((st) / KC) % 3 - 1) + (t) * 16) * stride + ((st) % KC) * 64)
 
   for (int nb = 0; nb < a.n_blocks; ++nb) {
     const int ch_wave = nb * 128 + wave * 32;
@@ -153,39 +152,58 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
       acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
     }
     if (active && !(DBG & 4)) {
-      // Fully unrolled, software pipelined by hand in half steps (4 image rows = 8 MFMAs): while one half
-      // runs, the four LDS fragments of the next half are in flight, and the two weight fragments of the
-      // next step are requested a full step ahead.  sched_barrier(0) fences keep the compiler from sinking
-      // those loads down to their first use (which would serialise every load with the MFMA that needs it).
+      // GEMM steps are grouped by (channel chunk kc, horizontal tap dx).  Inside a group the B fragment of output
+      // row t and vertical tap dy is the image-row fragment r = t + dy, so ONE LDS read per image row serves the
+      // three vertical taps (24 fragment reads per channel chunk instead of 72: the LDS pipe and the MFMA pipe
+      // were both saturated before), and the all-zero halo rows r = -1 and r = 8 are not multiplied at all
+      // (44 MFMAs per group instead of 48).  Fully unrolled; row fragments are requested two rows ahead, the six
+      // weight fragments of the next group at the start of the current one; sched_barrier(0) fences keep the
+      // compiler from sinking those loads down to their first use.
       const short8* wp = reinterpret_cast<const short8*>(wsrc) + ((size_t)nb * STEPS * 4 + wave) * 128 + lane;
-      short8 wb[2][2], av[2][4];
-      wb[0][0] = wp[0];
-      wb[0][1] = wp[64];
+      constexpr int GROUPS = 3 * KC;
+      // group g -> kc = g / 3, dxi = g % 3; weight step of vertical tap dyi: (dyi * 3 + dxi) * KC + kc
+#define ROWCONV_WSTEP(g, dyi) ((((dyi) * 3 + (g) % 3) * KC) + (g) / 3)
+      // LDS byte offset (relative to lane_base) of image row r at horizontal tap dxi of channel chunk kc
+#define ROWCONV_ROW(g, r) ((17 + (r) * 16 + ((g) % 3 - 1)) * stride + ((g) / 3) * 64)
+      short8 wg[2][3][2], av[3];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) av[0][t] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_OFF(0, t));
+      for (int dyi = 0; dyi < 3; ++dyi) {
+        wg[0][dyi][0] = wp[(size_t)ROWCONV_WSTEP(0, dyi) * 512];
+        wg[0][dyi][1] = wp[(size_t)ROWCONV_WSTEP(0, dyi) * 512 + 64];
+      }
+      av[0] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW(0, 0));
+      av[1] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW(0, 1));
 #pragma unroll
-      for (int hs = 0; hs < 2 * STEPS; ++hs) {
-        const int st = hs >> 1, half = hs & 1, cur = hs & 1, nxt = cur ^ 1, wcur = st & 1, wnxt = wcur ^ 1;
+      for (int i = 0; i < GROUPS * 8; ++i) {
+        const int g = i >> 3, r = i & 7, wc = g & 1, wn = wc ^ 1;
         __builtin_amdgcn_sched_barrier(0);
-        if (half == 0 && st + 1 < STEPS) {
-          wb[wnxt][0] = (DBG & 2) ? wb[wcur][0] : wp[(size_t)(st + 1) * 512];
-          wb[wnxt][1] = (DBG & 2) ? wb[wcur][1] : wp[(size_t)(st + 1) * 512 + 64];
-        }
-        if (hs + 1 < 2 * STEPS) {
+        if (r == 0 && g + 1 < GROUPS) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            av[nxt][t] = (DBG & 1) ? av[cur][t]
-                                   : *reinterpret_cast<const short8*>(lane_base + ROWCONV_OFF((hs + 1) >> 1, ((hs + 1) & 1) * 4 + t));
+          for (int dyi = 0; dyi < 3; ++dyi) {
+            wg[wn][dyi][0] = (DBG & 2) ? wg[wc][dyi][0] : wp[(size_t)ROWCONV_WSTEP(g + 1, dyi) * 512];
+            wg[wn][dyi][1] = (DBG & 2) ? wg[wc][dyi][1] : wp[(size_t)ROWCONV_WSTEP(g + 1, dyi) * 512 + 64];
+          }
         }
+        if (i + 2 < GROUPS * 8)
+          av[(i + 2) % 3] = (DBG & 1) ? av[i % 3]
+                                      : *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW((i + 2) >> 3, (i + 2) & 7));
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          // image rows >= H are all-zero halo rows: computing them keeps the loop branch-free
-          acc[half * 4 + t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[wcur][0], av[cur][t], acc[half * 4 + t][0], 0, 0, 0);
-          acc[half * 4 + t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[wcur][1], av[cur][t], acc[half * 4 + t][1], 0, 0, 0);
+        const short8 x = av[i % 3];
+        // image row r feeds output row r - 1 through the dy = +1 tap, row r through dy = 0, row r + 1 through dy = -1
+        if (r >= 1) {
+          acc[r - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][2][0], x, acc[r - 1][0], 0, 0, 0);
+          acc[r - 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][2][1], x, acc[r - 1][1], 0, 0, 0);
+        }
+        acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][1][0], x, acc[r][0], 0, 0, 0);
+        acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][1][1], x, acc[r][1], 0, 0, 0);
+        if (r <= 6) {
+          acc[r + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][0][0], x, acc[r + 1][0], 0, 0, 0);
+          acc[r + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][0][1], x, acc[r + 1][1], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+#undef ROWCONV_WSTEP
+#undef ROWCONV_ROW
     }
     __syncthreads();  // every wave is done reading the input tile (the output tile may alias it)
     float bias[8];
