@@ -41,6 +41,7 @@ struct RowConvArgs {
 namespace {
 constexpr int kInRows = 162;     // (8 + 2) * 16 + 2 halo-padded pixel rows
 constexpr int kOutStride = 272;  // bytes per row of the 128-channel output staging tile
+constexpr int kAhead = 2;        // image-row fragments requested ahead of the MFMAs that consume them
 
 // By value on purpose: an address-taken float[8] would live in scratch memory on every path.
 __device__ __noinline__ float4v act8_slow_rc(float4v v, int act) {
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
       // row t and vertical tap dy is the image-row fragment r = t + dy, so ONE LDS read per image row serves the
       // three vertical taps (24 fragment reads per channel chunk instead of 72: the LDS pipe and the MFMA pipe
       // were both saturated before), and the all-zero halo rows r = -1 and r = 8 are not multiplied at all
-      // (44 MFMAs per group instead of 48).  Fully unrolled; row fragments are requested two rows ahead, the six
+      // (44 MFMAs per group instead of 48).  Fully unrolled; row fragments are requested kAhead rows ahead, the six
       // weight fragments of the next group at the start of the current one; sched_barrier(0) fences keep the
       // compiler from sinking those loads down to their first use.
       const short8* wp = reinterpret_cast<const short8*>(wsrc) + ((size_t)nb * STEPS * 4 + wave) * 128 + lane;
@@ -165,14 +166,14 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
 #define ROWCONV_WSTEP(g, dyi) ((((dyi) * 3 + (g) % 3) * KC) + (g) / 3)
       // LDS byte offset (relative to lane_base) of image row r at horizontal tap dxi of channel chunk kc
 #define ROWCONV_ROW(g, r) ((17 + (r) * 16 + ((g) % 3 - 1)) * stride + ((g) / 3) * 64)
-      short8 wg[2][3][2], av[3];
+      short8 wg[2][3][2], av[kAhead + 1];
 #pragma unroll
       for (int dyi = 0; dyi < 3; ++dyi) {
         wg[0][dyi][0] = wp[(size_t)ROWCONV_WSTEP(0, dyi) * 512];
         wg[0][dyi][1] = wp[(size_t)ROWCONV_WSTEP(0, dyi) * 512 + 64];
       }
-      av[0] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW(0, 0));
-      av[1] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW(0, 1));
+#pragma unroll
+      for (int i = 0; i < kAhead; ++i) av[i] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW(i >> 3, i & 7));
 #pragma unroll
       for (int i = 0; i < GROUPS * 8; ++i) {
         const int g = i >> 3, r = i & 7, wc = g & 1, wn = wc ^ 1;
@@ -184,11 +185,12 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
             wg[wn][dyi][1] = (DBG & 2) ? wg[wc][dyi][1] : wp[(size_t)ROWCONV_WSTEP(g + 1, dyi) * 512 + 64];
           }
         }
-        if (i + 2 < GROUPS * 8)
-          av[(i + 2) % 3] = (DBG & 1) ? av[i % 3]
-                                      : *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW((i + 2) >> 3, (i + 2) & 7));
+        if (i + kAhead < GROUPS * 8)
+          av[(i + kAhead) % (kAhead + 1)] =
+              (DBG & 1) ? av[i % (kAhead + 1)]
+                        : *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW((i + kAhead) >> 3, (i + kAhead) & 7));
         __builtin_amdgcn_sched_barrier(0);
-        const short8 x = av[i % 3];
+        const short8 x = av[i % (kAhead + 1)];
         // image row r feeds output row r - 1 through the dy = +1 tap, row r through dy = 0, row r + 1 through dy = -1
         if (r >= 1) {
           acc[r - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][2][0], x, acc[r - 1][0], 0, 0, 0);
@@ -378,6 +380,7 @@ static int rowconv_impl(const void* in, const void* w, const float* bias, const 
     case 4: return launch_rowconv<4>(a, lds, stream);
     case 20: return launch_rowconv<20>(a, lds, stream);
     case 36: return launch_rowconv<36>(a, lds, stream);
+    case 48: return launch_rowconv<48>(a, lds, stream);
     case 52: return launch_rowconv<52>(a, lds, stream);
     default: return -14;
   }

@@ -20,7 +20,7 @@ from alphatriangle_amd.ops import hipbind as hb  # noqa: E402
 from alphatriangle_amd.ops.inference import pack_gemm_weights  # noqa: E402
 
 VARIANTS = {0: "full", 1: "no LDS reads", 2: "no weight loads", 4: "no main loop", 8: "no tap address math",
-            20: "no loop, no staging", 36: "no loop, no stores", 52: "no loop/staging/stores"}
+            20: "no loop, no staging", 48: "loop only (no staging, no stores)", 36: "no loop, no stores", 52: "no loop/staging/stores"}
 
 
 def main() -> None:
