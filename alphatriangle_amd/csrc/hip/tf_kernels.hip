@@ -190,14 +190,14 @@ struct AttnBlockArgs {
 
 // DBG != 0 instantiations are roofline probes (bench/attn_probe.py), bit mask: 1 no LayerNorm, 2 no K/V/Q GEMMs,
 // 4 no attention loop, 8 no output projection, 16 no input staging, 32 no output stores.
+// Attention half of the layer for sample b: leaves y = x + OutProj(MHA(LayerNorm1(x))) in registers, lane layout
+// y[t][n][j] = channel wave*32 + q4*8 + n*4 + j of token t*16 + l15 (rows >= HW hold finite padding values).
+// On return every wave is past its last read of the xn tile; the ao tile may still be read by other waves.
 template <int DBG>
-__global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* xn = smem;
-  unsigned char* ao = smem + kTileBytes;
+__device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char* xn, unsigned char* ao, int b,
+                                          float4v (&y)[8][2]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
-  const int b = blockIdx.x;
   const int HW = a.HW;
   const unsigned short* xg = a.x + (size_t)b * HW * kD;
 
@@ -322,20 +322,33 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   float bias[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bias[i] = a.bo[ch0 + i];
-  unsigned short* og = a.out + (size_t)b * HW * kD;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      y[t][0][j] = acc[t][0][j] + bias[j] + bf16_to_float((unsigned short)res.r[t][j]);
+      y[t][1][j] = acc[t][1][j] + bias[4 + j] + bf16_to_float((unsigned short)res.r[t][4 + j]);
+    }
+  }
+}
+
+template <int DBG>
+__global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.x;
+  float4v y[8][2];
+  attn_body<DBG>(a, smem, smem + kTileBytes, b, y);
+  const int ch0 = wave * 32 + q4 * 8;
+  unsigned short* og = a.out + (size_t)b * a.HW * kD;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     int r = t * 16 + l15;
     asm volatile("" : "+v"(r));
-    if (r >= HW) continue;
-    if ((DBG & 32) && acc[t][0][0] != 12345.f) continue;
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      o[j] = acc[t][0][j] + bias[j] + bf16_to_float((unsigned short)res.r[t][j]);
-      o[4 + j] = acc[t][1][j] + bias[4 + j] + bf16_to_float((unsigned short)res.r[t][4 + j]);
-    }
-    *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+    if (r >= a.HW) continue;
+    if ((DBG & 32) && y[t][0][0] != 12345.f) continue;
+    *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack8(y[t][0], y[t][1]);
   }
 }
 
@@ -469,6 +482,108 @@ __global__ __launch_bounds__(256, (TILES <= 4 ? 3 : 2)) void ffn_block_kernel(Ff
   }
 }
 
+// Whole encoder layer for one sample per workgroup: the attention half leaves y in registers, which become the
+// second FFN GEMM's accumulators (the residual stream stays fp32 and never goes to memory); bf16(y) goes to the xn
+// tile for LayerNorm2, the hidden halves go through the ao tile.  Against attn_block + ffn_block this saves the y
+// store, two y loads (FFN input and residual) and a kernel boundary per layer.
+struct EncoderLayerArgs {
+  AttnBlockArgs attn;   // attn.out is the layer output
+  const unsigned short* w1;
+  const float* b1;
+  const unsigned short* w2;
+  const float* b2;
+  const float* ln2_g;
+  const float* ln2_b;
+  int act;
+  float ln2_eps;
+};
+
+template <int HALVES>
+__global__ __launch_bounds__(256, 2) void encoder_layer_kernel(EncoderLayerArgs e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xn = smem;
+  unsigned char* hh = smem + kTileBytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.x;
+  const int HW = e.attn.HW;
+  const int ch0 = wave * 32 + q4 * 8;
+  float4v acc_o[8][2];
+  attn_body<0>(e.attn, xn, hh, b, acc_o);
+
+  const short8* w1p = reinterpret_cast<const short8*>(e.w1) + (size_t)wave * 128 + lane;
+  const short8* w2p = reinterpret_cast<const short8*>(e.w2) + (size_t)wave * 128 + lane;
+  WFrags wa, wb;
+  load_wfrags(wa, w1p);  // first W1 block: in flight during the y write and LayerNorm2
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    int r = t * 16 + l15;
+    asm volatile("" : "+v"(r));
+    if (r < HW) *reinterpret_cast<short8*>(xn + r * kStride + ch0 * 2) = pack8(acc_o[t][0], acc_o[t][1]);
+  }
+  __syncthreads();  // y tile complete; every wave is also past its out-projection reads of the other tile
+  layernorm_rows(xn, HW, e.ln2_g, e.ln2_b, e.ln2_eps, tid);
+  __syncthreads();
+  {
+    float b2v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b2v[i] = e.b2[ch0 + i];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc_o[t][0][j] += b2v[j];
+        acc_o[t][1][j] += b2v[4 + j];
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < HALVES; ++h) {
+    {
+      float bias[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bias[i] = e.b1[h * 128 + ch0 + i];
+      float4v acc_h[8][2];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        acc_h[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
+        acc_h[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
+      }
+      load_wfrags(wb, w2p + (size_t)h * 4 * 512);  // this half's W2 steps fly during the first GEMM
+      gemm_k128<false, 8>(acc_h, wa, xn, l15, q4);
+      if (h + 1 < HALVES) load_wfrags(wa, w1p + (size_t)(h + 1) * 4 * 512);  // next W1 block flies during the second GEMM
+      if (h > 0) __syncthreads();  // the previous half's second GEMM has finished reading the hidden tile
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc_h[t][0][j];
+          v[4 + j] = acc_h[t][1][j];
+        }
+        if (e.act == kActReLU) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752f));
+        }
+        *reinterpret_cast<short8*>(hh + (t * 16 + l15) * kStride + wave * 64 + q4 * 16) =
+            pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+      }
+    }
+    __syncthreads();
+    gemm_k128<false, 8>(acc_o, wb, hh, l15, q4);
+  }
+  unsigned short* og = e.attn.out + (size_t)b * HW * kD;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    int r = t * 16 + l15;
+    asm volatile("" : "+v"(r));
+    if (r < HW) *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack8(acc_o[t][0], acc_o[t][1]);
+  }
+}
+
 namespace {
 template <int DBG>
 int launch_attn(const AttnBlockArgs& a, hipStream_t stream) {
@@ -490,6 +605,16 @@ int launch_ffn(const FfnBlockArgs& a, hipStream_t stream) {
     attr = true;
   }
   hipLaunchKernelGGL((ffn_block_kernel<HALVES, TILES>), dim3((a.rows + rows_wg - 1) / rows_wg), dim3(256), lds, stream, a);
+  return (int)hipGetLastError();
+}
+template <int HALVES>
+int launch_layer(const EncoderLayerArgs& e, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)encoder_layer_kernel<HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
+    attr = true;
+  }
+  hipLaunchKernelGGL(encoder_layer_kernel<HALVES>, dim3(e.attn.B), dim3(256), 2 * kTileBytes, stream, e);
   return (int)hipGetLastError();
 }
 }  // namespace
@@ -795,6 +920,37 @@ int atri_ffn_block(const void* y, void* out, const void* w1, const float* b1, co
     case 2: return launch_ffn<2>(a, stream);
     case 3: return launch_ffn<3>(a, stream);
     case 4: return launch_ffn<4>(a, stream);
+    default: return -12;
+  }
+}
+
+// Whole pre-LN encoder layer, one launch: out = y + W2 act(W1 LN2(y)), y = x + OutProj(MHA(LN1(x))).
+// Up to 128 tokens, d_model 128, 4 heads, F in {128, 256, 384, 512}, ReLU or GELU.  x and out may not alias.
+int atri_encoder_layer(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                       const float* ln1_g, const float* ln1_b, float ln1_eps, const void* w1, const float* b1,
+                       const void* w2, const float* b2, const float* ln2_g, const float* ln2_b, float ln2_eps, int B,
+                       int HW, int D, int heads, int F, int act, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (D != kD || heads != 4 || HW > kRows || HW < 1) return -10;
+  if ((F & 127) != 0 || F < 128 || F > 512) return -12;
+  if (act != kActReLU && act != kActGELU) return -11;
+  if (x == out) return -13;  // the residual is read after other rows of the sample's output could have been written
+  EncoderLayerArgs e{};
+  e.attn = AttnBlockArgs{(const unsigned short*)x, (unsigned short*)out, (const unsigned short*)wqkv, bqkv,
+                         (const unsigned short*)wo, bo, ln1_g, ln1_b, B, HW, ln1_eps};
+  e.w1 = (const unsigned short*)w1;
+  e.b1 = b1;
+  e.w2 = (const unsigned short*)w2;
+  e.b2 = b2;
+  e.ln2_g = ln2_g;
+  e.ln2_b = ln2_b;
+  e.act = act;
+  e.ln2_eps = ln2_eps;
+  switch (F >> 7) {
+    case 1: return launch_layer<1>(e, stream);
+    case 2: return launch_layer<2>(e, stream);
+    case 3: return launch_layer<3>(e, stream);
+    case 4: return launch_layer<4>(e, stream);
     default: return -12;
   }
 }

@@ -17,8 +17,9 @@ Layer -> kernel map (default config, B leaves, HW = 120 tokens):
                                          residual / activation / positional epilogue)
   4-head attention                       attention_kernel         (MFMA, softmax in registers)
   encoder layer, d_model 128, 129..256 tok qkv_rows_kernel + attn_core_kernel + proj_rows_kernel + ffn_block_kernel
-  encoder layer, d_model 128 / <=128 tok attn_block_kernel + ffn_block_kernel (tf_kernels.hip; replaces the
-                                         five launches above with two, activations stay in LDS / registers)
+  encoder layer, d_model 128 / <=128 tok encoder_layer_kernel (tf_kernels.hip: one launch per layer, the residual stream
+                                         stays in registers between the attention and FFN halves); the two halves
+                                         also exist as attn_block_kernel + ffn_block_kernel
   final LayerNorm + flatten + shared FC  fc_rows_splitk_kernel (128-channel bodies: LN applied while staging the
   (K = 15390)                            rows, no flattened copy) + fc_finish_kernel; else rows_to_fc_kernel +
                                          fc_splitk_kernel
@@ -227,6 +228,7 @@ class InferenceEngine:
         )
         self.use_rowconv = True  # tests flip this to cover the generic tile kernel on small boards
         self.fuse_res_blocks = True  # tests flip this to compare the fused residual-block kernel with two launches
+        self.fuse_layer = True  # tests flip this to compare the one-launch encoder layer with attn_block + ffn_block
         self.use_fused_heads = True  # tests flip this to compare the fused tail kernel with the per-layer launches
         self.heads_fused = False
         self._store: list[torch.Tensor] = []
@@ -513,6 +515,15 @@ class InferenceEngine:
                 free = [i for i in range(5) if i != x]
                 q, t, y, h = free[0], free[1], free[2], free[3]
                 qkv, out, ff1, ff2 = tl["qkv"], tl["out"], tl["ff1"], tl["ff2"]
+                if self.fused_tf and self.fused_ffn and self.fuse_layer and self.act in (1, 2):
+                    # whole layer in one launch: bufs[x] -> bufs[q] (the residual stream stays in registers)
+                    hb.call("atri_encoder_layer", hb.ptr(bufs[x]), hb.ptr(bufs[q]), hb.ptr(qkv.w), hb.ptr(qkv.bias),
+                            hb.ptr(out.w), hb.ptr(out.bias), hb.ptr(qkv.ln_g), hb.ptr(qkv.ln_b), hb.f32(qkv.ln_eps),
+                            hb.ptr(ff1.w), hb.ptr(ff1.bias), hb.ptr(ff2.w), hb.ptr(ff2.bias), hb.ptr(ff1.ln_g), hb.ptr(ff1.ln_b),
+                            hb.f32(ff1.ln_eps), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads), hb.i32(ff1.cout),
+                            hb.i32(self.act))
+                    x = q
+                    continue
                 # ---- attention half: bufs[x] -> bufs[y]
                 if self.fused_tf:
                     hb.call("atri_attn_block", hb.ptr(bufs[x]), hb.ptr(bufs[y]), hb.ptr(qkv.w), hb.ptr(qkv.bias),

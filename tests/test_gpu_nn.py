@@ -381,6 +381,46 @@ def test_fused_heads_kernel_matches_per_layer_launches(act, batch):
     assert (v1 - ref_v).abs().max().item() < 0.25
 
 
+@pytest.mark.parametrize("act,rows,cols,batch", [("ReLU", 8, 15, 21), ("GELU", 8, 15, 5), ("ReLU", 5, 9, 33)])
+def test_one_launch_encoder_layer_matches_two_kernel_path_and_torch(act, rows, cols, batch):
+    """encoder_layer_kernel against attn_block + ffn_block (same weights; the fused kernel keeps the residual stream in
+    fp32 registers instead of rounding it to bf16 in memory) and against the fp32 PyTorch module."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(13)
+    dev = _dev()
+    env = EnvConfig(ROWS=rows, COLS=cols, PLAYABLE_RANGE_PER_ROW=[(0, cols)] * rows)
+    mc = ModelConfig(ACTIVATION_FUNCTION=act)
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev)
+    with torch.no_grad():  # non-trivial LayerNorm affine parts and biases
+        for m in net.model.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.normal_(1.0, 0.2)
+                m.bias.normal_(0, 0.2)
+            if isinstance(m, torch.nn.Linear):
+                m.bias.normal_(0, 0.1)
+    net.sync_inference_weights()
+    eng = net.engine
+    assert eng is not None and eng.fused_tf and eng.fused_ffn and eng.fuse_layer
+    grid = torch.randint(-1, 2, (batch, 1, rows, cols), device=dev).float()
+    other = torch.rand(batch, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    l1, v1 = (t.clone() for t in eng.forward(grid, other))
+    eng.fuse_layer = False
+    try:
+        l2, v2 = (t.clone() for t in eng.forward(grid, other))
+    finally:
+        eng.fuse_layer = True
+    torch.cuda.synchronize()
+    assert (l1 - l2).abs().max().item() < 0.05, (l1 - l2).abs().max().item()
+    assert (v1 - v2).abs().max().item() < 0.1
+    net.model.eval()
+    with torch.no_grad():
+        pl, vl = net.model(grid, other)
+    ref_v = (torch.softmax(vl.float(), 1) * net.support.to(dev)).sum(1)
+    assert (l1 - pl).abs().max().item() < 0.15, (l1 - pl).abs().max().item()
+    assert (v1 - ref_v).abs().max().item() < 0.25
+
+
 @pytest.mark.parametrize("hw", [252, 120, 64])
 def test_rows_attention_path_matches_torch(hw):
     """qkv_rows + attn_core + proj_rows (+ ffn_block) vs nn.TransformerEncoderLayer(norm_first=True) in fp32."""
