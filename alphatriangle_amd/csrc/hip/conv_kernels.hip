@@ -33,9 +33,11 @@ struct RowConvArgs {
   const float* w_first;  // [9][Cin] f32 (BatchNorm folded)
   const float* b_first;  // [Cin]
   int first_act, aux_off;
-  // PAIR instantiation only: second convolution of a residual block (same geometry, Cin = Cout = 128)
+  // PAIR instantiation only: the second convolution (residual block: in place, Cin = Cout = 128; conv stem: Cin2
+  // channels in a second halo tile at tile2_off)
   const unsigned short* w2;
   const float* bias2;
+  int tile2_off;
 };
 
 namespace {
@@ -50,6 +52,70 @@ __device__ __noinline__ float4v act8_slow_rc(float4v v, int act) {
 }
 }  // namespace
 
+namespace {
+// One 3x3 convolution of this wave's 32 output channels over the halo tile behind lane_base:
+// acc[t][n] += W x tile for the 8 image rows t.
+template <int CIN, int DBG>
+__device__ __forceinline__ void rowconv_mainloop(float4v (&acc)[8][2], const unsigned short* __restrict__ wsrc, int nb,
+                                                 const unsigned char* lane_base, int wave, int lane) {
+  constexpr int stride = CIN * 2 + 32;
+  constexpr int KC = CIN / 32, STEPS = 9 * KC;
+  // GEMM steps are grouped by (channel chunk kc, horizontal tap dx).  Inside a group the B fragment of output
+  // row t and vertical tap dy is the image-row fragment r = t + dy, so ONE LDS read per image row serves the
+  // three vertical taps (24 fragment reads per channel chunk instead of 72: the LDS pipe and the MFMA pipe
+  // were both saturated before), and the all-zero halo rows r = -1 and r = 8 are not multiplied at all
+  // (44 MFMAs per group instead of 48).  Fully unrolled; row fragments are requested kAhead rows ahead, the six
+  // weight fragments of the next group at the start of the current one; sched_barrier(0) fences keep the
+  // compiler from sinking those loads down to their first use.
+  const short8* wp = reinterpret_cast<const short8*>(wsrc) + ((size_t)nb * STEPS * 4 + wave) * 128 + lane;
+  constexpr int GROUPS = 3 * KC;
+  // group g -> kc = g / 3, dxi = g % 3; weight step of vertical tap dyi: (dyi * 3 + dxi) * KC + kc
+#define ROWCONV_WSTEP(g, dyi) ((((dyi) * 3 + (g) % 3) * KC) + (g) / 3)
+  // LDS byte offset (relative to lane_base) of image row r at horizontal tap dxi of channel chunk kc
+#define ROWCONV_ROW(g, r) ((17 + (r) * 16 + ((g) % 3 - 1)) * stride + ((g) / 3) * 64)
+  short8 wg[2][3][2], av[kAhead + 1];
+#pragma unroll
+  for (int dyi = 0; dyi < 3; ++dyi) {
+    wg[0][dyi][0] = wp[(size_t)ROWCONV_WSTEP(0, dyi) * 512];
+    wg[0][dyi][1] = wp[(size_t)ROWCONV_WSTEP(0, dyi) * 512 + 64];
+  }
+#pragma unroll
+  for (int i = 0; i < kAhead; ++i) av[i] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW(i >> 3, i & 7));
+#pragma unroll
+  for (int i = 0; i < GROUPS * 8; ++i) {
+    const int g = i >> 3, r = i & 7, wc = g & 1, wn = wc ^ 1;
+    __builtin_amdgcn_sched_barrier(0);
+    if (r == 0 && g + 1 < GROUPS) {
+#pragma unroll
+      for (int dyi = 0; dyi < 3; ++dyi) {
+        wg[wn][dyi][0] = (DBG & 2) ? wg[wc][dyi][0] : wp[(size_t)ROWCONV_WSTEP(g + 1, dyi) * 512];
+        wg[wn][dyi][1] = (DBG & 2) ? wg[wc][dyi][1] : wp[(size_t)ROWCONV_WSTEP(g + 1, dyi) * 512 + 64];
+      }
+    }
+    if (i + kAhead < GROUPS * 8)
+      av[(i + kAhead) % (kAhead + 1)] =
+          (DBG & 1) ? av[i % (kAhead + 1)]
+                    : *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW((i + kAhead) >> 3, (i + kAhead) & 7));
+    __builtin_amdgcn_sched_barrier(0);
+    const short8 x = av[i % (kAhead + 1)];
+    // image row r feeds output row r - 1 through the dy = +1 tap, row r through dy = 0, row r + 1 through dy = -1
+    if (r >= 1) {
+      acc[r - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][2][0], x, acc[r - 1][0], 0, 0, 0);
+      acc[r - 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][2][1], x, acc[r - 1][1], 0, 0, 0);
+    }
+    acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][1][0], x, acc[r][0], 0, 0, 0);
+    acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][1][1], x, acc[r][1], 0, 0, 0);
+    if (r <= 6) {
+      acc[r + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][0][0], x, acc[r + 1][0], 0, 0, 0);
+      acc[r + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][0][1], x, acc[r + 1][1], 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#undef ROWCONV_WSTEP
+#undef ROWCONV_ROW
+}
+}  // namespace
+
 // DBG != 0 instantiations are roofline probes (bench/conv_probe.py), bit mask: 1 no LDS fragment reads,
 // 2 no weight-fragment loads, 4 no main loop, 16 no input staging loads, 32 no write-back phase.
 // FIRST: the input tile is not read from memory but computed from the raw board (first conv layer, Cin_first = 1),
@@ -59,7 +125,9 @@ __device__ __noinline__ float4v act8_slow_rc(float4v v, int act) {
 // which is the tile's row layout; the halo stays zero), the second convolution runs from there and takes the skip
 // connection from the block input in memory.  Saves the write-back phase of one convolution, the staging phase
 // of the other and a kernel boundary per block.
-template <int CIN, int DBG, bool FIRST = false, bool PAIR = false>
+// PAIR with CIN2 != CIN: two consecutive convolutions of different widths (the conv stem: CIN -> CIN2 -> Cout); the
+// first one's output goes into a second halo tile of CIN2 channels instead of back in place.
+template <int CIN, int DBG, bool FIRST = false, bool PAIR = false, int CIN2 = CIN>
 __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,8 +136,12 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
   // row pitch = Cin*2 + 32 bytes = an even, non-multiple-of-4 count of 16-byte slots: the 16 lanes that one
   // ds_read_b128 cycle serves (8 rows at slot q, 8 rows at slot q+1) then hit 16 different bank quads for every tap
   constexpr int stride = CIN * 2 + 32;
-  constexpr int KC = CIN / 32, STEPS = 9 * KC;
+  constexpr int stride2 = CIN2 * 2 + 32;
   const int H = a.H, W = a.W;
+  unsigned char* tile2 = smem + (CIN2 != CIN ? a.tile2_off : 0);
+  if (PAIR && CIN2 != CIN) {  // the second tile's halo has to be zero; its interior is written by the first convolution
+    for (int c = tid; c < kInRows * stride2 / 16; c += 256) reinterpret_cast<uint4*>(tile2)[c] = make_uint4(0, 0, 0, 0);
+  }
 
   // ---- stage the sample with its zero halo; eight global loads in flight per thread ----
   if (FIRST) {
@@ -137,75 +209,29 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
   // Fragment addresses are lane_base + a compile-time offset after unrolling: every ds_read of the main loop
   // uses an immediate offset.
   const unsigned char* lane_base = smem + l15 * stride + q4 * 16;
+  const unsigned char* lane_base2 = tile2 + l15 * stride2 + q4 * 16;
   unsigned char* otile = smem + a.out_off;
 
   for (int nb = 0; nb < a.n_blocks; ++nb) {
     const int ch_wave = nb * 128 + wave * 32;
-    const bool active = ch_wave < a.Cout;  // wave-uniform
     float4v acc[8][2];
-#pragma unroll 1
+    // same-width pair: one copy of the unrolled main loop, run twice; different widths: two straight-line stages
+#pragma unroll(CIN2 != CIN ? 2 : 1)
     for (int stage = 0; stage < (PAIR ? 2 : 1); ++stage) {
     const unsigned short* wsrc = (PAIR && stage == 1) ? a.w2 : a.w;
     const float* bsrc = (PAIR && stage == 1) ? a.bias2 : a.bias;
+    // wave-uniform; the first convolution of a pair has CIN2 output channels
+    const bool active = (PAIR && stage == 0) ? (wave * 32 < CIN2) : (ch_wave < a.Cout);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
       acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
     }
     if (active && !(DBG & 4)) {
-      // GEMM steps are grouped by (channel chunk kc, horizontal tap dx).  Inside a group the B fragment of output
-      // row t and vertical tap dy is the image-row fragment r = t + dy, so ONE LDS read per image row serves the
-      // three vertical taps (24 fragment reads per channel chunk instead of 72: the LDS pipe and the MFMA pipe
-      // were both saturated before), and the all-zero halo rows r = -1 and r = 8 are not multiplied at all
-      // (44 MFMAs per group instead of 48).  Fully unrolled; row fragments are requested kAhead rows ahead, the six
-      // weight fragments of the next group at the start of the current one; sched_barrier(0) fences keep the
-      // compiler from sinking those loads down to their first use.
-      const short8* wp = reinterpret_cast<const short8*>(wsrc) + ((size_t)nb * STEPS * 4 + wave) * 128 + lane;
-      constexpr int GROUPS = 3 * KC;
-      // group g -> kc = g / 3, dxi = g % 3; weight step of vertical tap dyi: (dyi * 3 + dxi) * KC + kc
-#define ROWCONV_WSTEP(g, dyi) ((((dyi) * 3 + (g) % 3) * KC) + (g) / 3)
-      // LDS byte offset (relative to lane_base) of image row r at horizontal tap dxi of channel chunk kc
-#define ROWCONV_ROW(g, r) ((17 + (r) * 16 + ((g) % 3 - 1)) * stride + ((g) / 3) * 64)
-      short8 wg[2][3][2], av[kAhead + 1];
-#pragma unroll
-      for (int dyi = 0; dyi < 3; ++dyi) {
-        wg[0][dyi][0] = wp[(size_t)ROWCONV_WSTEP(0, dyi) * 512];
-        wg[0][dyi][1] = wp[(size_t)ROWCONV_WSTEP(0, dyi) * 512 + 64];
-      }
-#pragma unroll
-      for (int i = 0; i < kAhead; ++i) av[i] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW(i >> 3, i & 7));
-#pragma unroll
-      for (int i = 0; i < GROUPS * 8; ++i) {
-        const int g = i >> 3, r = i & 7, wc = g & 1, wn = wc ^ 1;
-        __builtin_amdgcn_sched_barrier(0);
-        if (r == 0 && g + 1 < GROUPS) {
-#pragma unroll
-          for (int dyi = 0; dyi < 3; ++dyi) {
-            wg[wn][dyi][0] = (DBG & 2) ? wg[wc][dyi][0] : wp[(size_t)ROWCONV_WSTEP(g + 1, dyi) * 512];
-            wg[wn][dyi][1] = (DBG & 2) ? wg[wc][dyi][1] : wp[(size_t)ROWCONV_WSTEP(g + 1, dyi) * 512 + 64];
-          }
-        }
-        if (i + kAhead < GROUPS * 8)
-          av[(i + kAhead) % (kAhead + 1)] =
-              (DBG & 1) ? av[i % (kAhead + 1)]
-                        : *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW((i + kAhead) >> 3, (i + kAhead) & 7));
-        __builtin_amdgcn_sched_barrier(0);
-        const short8 x = av[i % (kAhead + 1)];
-        // image row r feeds output row r - 1 through the dy = +1 tap, row r through dy = 0, row r + 1 through dy = -1
-        if (r >= 1) {
-          acc[r - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][2][0], x, acc[r - 1][0], 0, 0, 0);
-          acc[r - 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][2][1], x, acc[r - 1][1], 0, 0, 0);
-        }
-        acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][1][0], x, acc[r][0], 0, 0, 0);
-        acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][1][1], x, acc[r][1], 0, 0, 0);
-        if (r <= 6) {
-          acc[r + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][0][0], x, acc[r + 1][0], 0, 0, 0);
-          acc[r + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][0][1], x, acc[r + 1][1], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#undef ROWCONV_WSTEP
-#undef ROWCONV_ROW
+      if (PAIR && stage == 1 && CIN2 != CIN)
+        rowconv_mainloop<CIN2, DBG>(acc, wsrc, nb, lane_base2, wave, lane);
+      else
+        rowconv_mainloop<CIN, DBG>(acc, wsrc, nb, lane_base, wave, lane);
     }
     __syncthreads();  // every wave is done reading the input tile (the output tile may alias it)
     float bias[8];
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
             lo = act8_slow_rc(lo, a.act);
             hi = act8_slow_rc(hi, a.act);
           }
-          *reinterpret_cast<short8*>(smem + (17 + t * 16 + l15) * stride + wave * 64 + q4 * 16) =
+          *reinterpret_cast<short8*>(tile2 + (17 + t * 16 + l15) * stride2 + wave * 64 + q4 * 16) =
               pack_bf16x8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
         }
       }
@@ -321,14 +347,14 @@ int atri_rowconv_supported(int H, int W, int Cin, int Cout) {
 }  // extern "C"
 
 namespace {
-template <int CIN, int DBG, bool FIRST, bool PAIR = false>
+template <int CIN, int DBG, bool FIRST, bool PAIR = false, int CIN2 = CIN>
 int launch_rowconv_inst(const RowConvArgs& a, int lds, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)rowconv_kernel<CIN, DBG, FIRST, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)rowconv_kernel<CIN, DBG, FIRST, PAIR, CIN2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((rowconv_kernel<CIN, DBG, FIRST, PAIR>), dim3(a.B), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((rowconv_kernel<CIN, DBG, FIRST, PAIR, CIN2>), dim3(a.B), dim3(256), lds, stream, a);
   return hip_err(hipGetLastError());
 }
 
@@ -465,6 +491,46 @@ int atri_rowconv_pair(const void* in, const void* w1, const float* b1, const voi
   for (int p = 0; p < a.HW; ++p)
     if (((p * a.ymagic) >> 16) != p / W) return -12;
   return launch_rowconv_inst<128, 0, false, true>(a, lds, stream);
+}
+
+// Conv stem in one launch: board plane -> conv(1 -> C0) -> conv(C0 -> C1) -> conv(C1 -> C2), every layer followed by
+// the activation; only the last layer's output goes to memory.  (C0, C1, C2) = (32, 64, 128).
+// w_first [9][C0] / b_first [C0]: first layer (evaluated while staging); (w1, b1), (w2, b2): packed second and third layer.
+int atri_rowconv_stem(const float* grid, const float* w_first, const float* b_first, const void* w1, const float* b1,
+                      const void* w2, const float* b2, const float* post_add, void* out, int B, int H, int W, int C0, int C1,
+                      int C2, int act, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (C0 != 32 || C1 != 64 || C2 != 128 || !atri_rowconv_supported(H, W, C0, C1) || H * W > 128) return -10;
+  RowConvArgs a{};
+  a.w = (const unsigned short*)w1;
+  a.bias = b1;
+  a.w2 = (const unsigned short*)w2;
+  a.bias2 = b2;
+  a.post_add = post_add;
+  a.out = (unsigned short*)out;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.HW = H * W;
+  a.Cin = C0;
+  a.Cout = C2;
+  a.act = act;
+  a.n_blocks = 1;
+  a.grid = grid;
+  a.w_first = w_first;
+  a.b_first = b_first;
+  a.first_act = act;
+  const int tile1 = kInRows * (C0 * 2 + 32), tile2 = kInRows * (C1 * 2 + 32);
+  const int out_bytes = 128 * kOutStride;
+  a.tile2_off = (tile1 + 15) & ~15;
+  a.out_off = 0;  // the output staging tile reuses both input tiles once the last main loop is done
+  int lds = a.tile2_off + tile2 > out_bytes ? a.tile2_off + tile2 : out_bytes;
+  a.aux_off = (lds + 15) & ~15;
+  lds = a.aux_off + (128 + 10 * C0) * 4;
+  a.ymagic = 65536 / W + 1;
+  for (int p = 0; p < a.HW; ++p)
+    if (((p * a.ymagic) >> 16) != p / W) return -12;
+  return launch_rowconv_inst<32, 0, true, true, 64>(a, lds, stream);
 }
 
 // Roofline probe: the same launch with ingredients removed (see the kernel's DBG parameter).

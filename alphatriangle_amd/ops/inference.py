@@ -8,7 +8,8 @@ reference is the eval-mode PyTorch module (models/model.py); the network itself
 is the reference's (alphatriangle/nn/model.py:109-297).
 
 Layer -> kernel map (default config, B leaves, HW = 120 tokens):
-  conv stem layer 0 (Cin = 1)            evaluated inside the staging of layer 1's rowconv_kernel (boards up to 8x15),
+  conv stem 1 -> 32 -> 64 -> 128         rowconv_kernel<32, FIRST, PAIR, 64>: one launch, intermediates in LDS halo tiles
+  conv stem layer 0 (Cin = 1), others    evaluated inside the staging of layer 1's rowconv_kernel (boards up to 8x15),
                                          else conv_first_kernel (VALU, memory bound)
   residual blocks (128 channels)         rowconv_kernel<PAIR>: both convolutions in one launch, intermediate in LDS
   conv stem 1.., residual convs          rowconv_kernel (boards up to 8x15: halo tile in LDS, one sample per
@@ -228,6 +229,7 @@ class InferenceEngine:
         )
         self.use_rowconv = True  # tests flip this to cover the generic tile kernel on small boards
         self.fuse_res_blocks = True  # tests flip this to compare the fused residual-block kernel with two launches
+        self.fuse_stem = True  # tests flip this to compare the one-launch conv stem with per-layer launches
         self.fuse_layer = True  # tests flip this to compare the one-launch encoder layer with attn_block + ffn_block
         self.use_fused_heads = True  # tests flip this to compare the fused tail kernel with the per-layer launches
         self.heads_fused = False
@@ -467,7 +469,20 @@ class InferenceEngine:
             self.use_rowconv and body and body[0][0] == "plain" and body[0][1].post_add is None and body[0][1].taps == 9
             and self.H <= 8 and self.W <= 15 and self.c0 in (32, 64, 128) and _pow2(body[0][1].cout)
         )
-        if fuse_first:
+        fuse_stem = (
+            fuse_first and self.fuse_stem and len(body) >= 2 and body[1][0] == "plain" and self.c0 == 32
+            and body[0][1].cout == 64 and body[1][1].cin == 64 and body[1][1].cout == 128 and body[1][1].taps == 9
+            and body[0][1].act == self.act and body[1][1].act == self.act and body[1][1].ln_g is None and self.HW <= 128
+        )
+        if fuse_stem:
+            # whole conv stem (1 -> 32 -> 64 -> 128 channels) in one launch: only the last layer's output goes to memory
+            l1, l2 = body[0][1], body[1][1]
+            hb.call("atri_rowconv_stem", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.ptr(l1.w), hb.ptr(l1.bias),
+                    hb.ptr(l2.w), hb.ptr(l2.bias), hb.ptr(l2.post_add), hb.ptr(bufs[1]), hb.i32(B), hb.i32(self.H), hb.i32(self.W),
+                    hb.i32(self.c0), hb.i32(l1.cout), hb.i32(l2.cout), hb.i32(self.act))
+            cur = 1
+            body = body[2:]
+        elif fuse_first:
             # first layer (1 input channel) evaluated inside the staging of the second one: no separate kernel
             l1 = body[0][1]
             hb.call("atri_rowconv_first", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.i32(self.act), hb.ptr(l1.w),

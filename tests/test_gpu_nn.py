@@ -324,10 +324,12 @@ def test_fused_residual_block_matches_two_launches_and_torch(act, rows, cols):
     other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
     l1, v1 = (t.clone() for t in eng.forward(grid, other))
     eng.fuse_res_blocks = False
+    eng.fuse_stem = False  # also compares the one-launch conv stem with its per-layer launches
     try:
         l2, v2 = (t.clone() for t in eng.forward(grid, other))
     finally:
         eng.fuse_res_blocks = True
+        eng.fuse_stem = True
     torch.cuda.synchronize()
     assert (l1 - l2).abs().max().item() < 0.03, (l1 - l2).abs().max().item()
     assert (v1 - v2).abs().max().item() < 0.05
