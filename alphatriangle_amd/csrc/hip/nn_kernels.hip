@@ -503,23 +503,24 @@ __global__ __launch_bounds__(256, 2) void fc_splitk_kernel(const unsigned short*
 // it is staged into LDS (16 lanes per row, statistics by xor-shuffles), and the "other" features come from a
 // small bf16 side buffer as the last K steps.  Replaces rows_to_fc + fc_splitk and their 2 x 126 MB round trip.
 // steps_per_split is a multiple of 4, so every staged chunk of 4 K-steps is exactly one pixel row.
+template <int MT>
 __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned short* __restrict__ rows /*[B][HW][128]*/,
                                                                 const unsigned short* __restrict__ other /*[B][other_pad]*/,
                                                                 const float* __restrict__ g, const float* __restrict__ bt,
                                                                 float eps, const unsigned short* __restrict__ Wp,
                                                                 float* __restrict__ slabs, int B, int HW, int other_pad,
                                                                 int N, int steps_per_split) {
-  __shared__ __attribute__((aligned(16))) unsigned char xs[64 * 272];
+  __shared__ __attribute__((aligned(16))) unsigned char xs[MT * 16 * 272];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
-  const int b0 = blockIdx.x * 64;
+  const int b0 = blockIdx.x * (MT * 16);
   const int feat_steps = HW * 4;
   const int total_steps = feat_steps + (other_pad >> 5);
   const int s_begin = blockIdx.y * steps_per_split;
   const int s_end = min(s_begin + steps_per_split, total_steps);
-  float4v acc[4][2];
+  float4v acc[MT][2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < MT; ++t) {
     acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
     acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
   }
@@ -532,14 +533,16 @@ __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned s
     gg[j] = g != nullptr ? g[(tid & 15) * 8 + j] : 1.f;
     bb[j] = g != nullptr ? bt[(tid & 15) * 8 + j] : 0.f;
   }
-  for (int s0 = s_begin; s0 < s_end; s0 += 4) {
-    __syncthreads();
-    uint4 v[4];
+  // One pixel row (4 K-steps) of MT * 16 samples per iteration (128 samples per workgroup halve the weight reads
+  // from L2, which are twice the activation bytes at 64).  The rows of iteration i+1 and the weight fragments of
+  // iteration i are requested before the LayerNorm / MFMA work of iteration i, so neither HBM nor L2 latency is
+  // exposed once the loop is running.
+  auto load_rows = [&](int s0, uint4 (&v)[MT]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       const int c = tid + i * 256, r = c >> 4, cc = c & 15;
       v[i] = make_uint4(0, 0, 0, 0);
-      if (b0 + r < B) {
+      if (s0 < s_end && b0 + r < B) {
         if (s0 < feat_steps) {
           v[i] = *reinterpret_cast<const uint4*>(rows + ((size_t)(b0 + r) * HW + (s0 >> 2)) * 128 + cc * 8);
         } else if ((s0 - feat_steps) * 32 + cc * 8 < other_pad) {
@@ -547,8 +550,22 @@ __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned s
         }
       }
     }
+  };
+  uint4 v[MT];
+  load_rows(s_begin, v);
+  for (int s0 = s_begin; s0 < s_end; s0 += 4) {
+    short8 wf[4][2];
+    if (wave_active) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int ks = 0; ks < 4; ++ks) {
+        const int step = min(s0 + ks, s_end - 1);  // steps beyond the split are loaded but not multiplied
+        wf[ks][0] = wp[(size_t)step * 512];
+        wf[ks][1] = wp[(size_t)step * 512 + 64];
+      }
+    }
+    __syncthreads();  // the previous iteration's MFMAs are done reading the tile
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
       const int c = tid + i * 256, r = c >> 4, cc = c & 15;
       short8 x = __builtin_bit_cast(short8, v[i]);
       if (g != nullptr && s0 < feat_steps) {  // block-uniform branch: all 16 lanes of a row take it together
@@ -573,18 +590,16 @@ __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned s
       *reinterpret_cast<short8*>(xs + r * 272 + cc * 16) = x;
     }
     __syncthreads();
+    load_rows(s0 + 4, v);  // next pixel row: in flight during the MFMAs below
     if (!wave_active) continue;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int step = s0 + ks;
-      if (step >= s_end) break;
-      const short8 w0 = wp[(size_t)step * 512];
-      const short8 w1 = wp[(size_t)step * 512 + 64];
+      if (s0 + ks >= s_end) break;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < MT; ++t) {
         const short8 xv = *reinterpret_cast<const short8*>(xs + (t * 16 + l15) * 272 + ks * 64 + q4 * 16);
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xv, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xv, acc[t][1], 0, 0, 0);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][0], xv, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][1], xv, acc[t][1], 0, 0, 0);
       }
     }
   }
@@ -592,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned s
   float* slab = slabs + (size_t)blockIdx.y * B * 128;
   const int ch0 = wave * 32 + q4 * 8;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < MT; ++t) {
     const int bi = b0 + t * 16 + l15;
     if (bi >= B) continue;
     float* op = slab + (size_t)bi * 128 + ch0;
@@ -814,9 +829,14 @@ int atri_fc_rows_splitk(const void* rows, const void* other, const float* g, con
   if (D != 128 || (other_pad & 31) != 0 || N > 128 || (N & 31) != 0) return -10;
   if ((steps_per_split & 3) != 0 || steps_per_split <= 0) return -11;
   if ((long long)SK * steps_per_split < (long long)HW * 4 + (other_pad >> 5)) return -12;
-  hipLaunchKernelGGL(fc_rows_splitk_kernel, dim3((B + 63) / 64, SK), dim3(256), 0, stream, (const unsigned short*)rows,
-                     (const unsigned short*)other, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
-                     steps_per_split);
+  if (B >= 2048)  // enough samples to fill the chip with 128-sample workgroups
+    hipLaunchKernelGGL(fc_rows_splitk_kernel<8>, dim3((B + 127) / 128, SK), dim3(256), 0, stream, (const unsigned short*)rows,
+                       (const unsigned short*)other, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
+                       steps_per_split);
+  else
+    hipLaunchKernelGGL(fc_rows_splitk_kernel<4>, dim3((B + 63) / 64, SK), dim3(256), 0, stream, (const unsigned short*)rows,
+                       (const unsigned short*)other, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
+                       steps_per_split);
   return hip_err(hipGetLastError());
 }
 
