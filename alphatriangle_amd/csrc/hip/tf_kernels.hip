@@ -482,6 +482,91 @@ __global__ __launch_bounds__(256, (TILES <= 4 ? 3 : 2)) void ffn_block_kernel(Ff
   }
 }
 
+// Second half of a pre-LN encoder layer for a tile of up to 128 token rows whose y = x + attention output sits in
+// registers (acc_o, lane layout of gemm_k128<false>): bf16(y) -> xn tile -> LayerNorm2 in place -> hidden halves
+// through the hh tile -> second GEMM accumulates onto y (+ b2) -> rows < nrows stored at og.  On entry every wave
+// may still be reading hh (the first __syncthreads below orders that before the first hidden write).
+template <int HALVES>
+__device__ __forceinline__ void ffn_tail(float4v (&acc_o)[8][2], unsigned char* xn, unsigned char* hh, int nrows,
+                                         const unsigned short* __restrict__ w1, const float* __restrict__ b1,
+                                         const unsigned short* __restrict__ w2, const float* __restrict__ b2,
+                                         const float* __restrict__ ln2_g, const float* __restrict__ ln2_b, float ln2_eps,
+                                         int act, unsigned short* __restrict__ og) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int ch0 = wave * 32 + q4 * 8;
+  const short8* w1p = reinterpret_cast<const short8*>(w1) + (size_t)wave * 128 + lane;
+  const short8* w2p = reinterpret_cast<const short8*>(w2) + (size_t)wave * 128 + lane;
+  WFrags wa, wb;
+  load_wfrags(wa, w1p);  // first W1 block: in flight during the y write and LayerNorm2
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    int r = t * 16 + l15;
+    asm volatile("" : "+v"(r));
+    if (r < nrows) *reinterpret_cast<short8*>(xn + r * kStride + ch0 * 2) = pack8(acc_o[t][0], acc_o[t][1]);
+  }
+  __syncthreads();  // y tile complete; every wave is also past its out-projection reads of the other tile
+  layernorm_rows(xn, nrows, ln2_g, ln2_b, ln2_eps, tid);
+  __syncthreads();
+  {
+    float b2v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b2v[i] = b2[ch0 + i];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc_o[t][0][j] += b2v[j];
+        acc_o[t][1][j] += b2v[4 + j];
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < HALVES; ++h) {
+    {
+      float bias[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bias[i] = b1[h * 128 + ch0 + i];
+      float4v acc_h[8][2];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        acc_h[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
+        acc_h[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
+      }
+      load_wfrags(wb, w2p + (size_t)h * 4 * 512);  // this half's W2 steps fly during the first GEMM
+      gemm_k128<false, 8>(acc_h, wa, xn, l15, q4);
+      if (h + 1 < HALVES) load_wfrags(wa, w1p + (size_t)(h + 1) * 4 * 512);  // next W1 block flies during the second GEMM
+      if (h > 0) __syncthreads();  // the previous half's second GEMM has finished reading the hidden tile
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc_h[t][0][j];
+          v[4 + j] = acc_h[t][1][j];
+        }
+        if (act == kActReLU) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752f));
+        }
+        *reinterpret_cast<short8*>(hh + (t * 16 + l15) * kStride + wave * 64 + q4 * 16) =
+            pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+      }
+    }
+    __syncthreads();
+    gemm_k128<false, 8>(acc_o, wb, hh, l15, q4);
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    int r = t * 16 + l15;
+    asm volatile("" : "+v"(r));
+    if (r < nrows) *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack8(acc_o[t][0], acc_o[t][1]);
+  }
+}
+
 // Whole encoder layer for one sample per workgroup: the attention half leaves y in registers, which become the
 // second FFN GEMM's accumulators (the residual stream stays fp32 and never goes to memory); bf16(y) goes to the xn
 // tile for LayerNorm2, the hidden halves go through the ao tile.  Against attn_block + ffn_block this saves the y
@@ -511,77 +596,8 @@ __global__ __launch_bounds__(256, 2) void encoder_layer_kernel(EncoderLayerArgs 
   float4v acc_o[8][2];
   attn_body<0>(e.attn, xn, hh, b, acc_o);
 
-  const short8* w1p = reinterpret_cast<const short8*>(e.w1) + (size_t)wave * 128 + lane;
-  const short8* w2p = reinterpret_cast<const short8*>(e.w2) + (size_t)wave * 128 + lane;
-  WFrags wa, wb;
-  load_wfrags(wa, w1p);  // first W1 block: in flight during the y write and LayerNorm2
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    int r = t * 16 + l15;
-    asm volatile("" : "+v"(r));
-    if (r < HW) *reinterpret_cast<short8*>(xn + r * kStride + ch0 * 2) = pack8(acc_o[t][0], acc_o[t][1]);
-  }
-  __syncthreads();  // y tile complete; every wave is also past its out-projection reads of the other tile
-  layernorm_rows(xn, HW, e.ln2_g, e.ln2_b, e.ln2_eps, tid);
-  __syncthreads();
-  {
-    float b2v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) b2v[i] = e.b2[ch0 + i];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc_o[t][0][j] += b2v[j];
-        acc_o[t][1][j] += b2v[4 + j];
-      }
-    }
-  }
-#pragma unroll
-  for (int h = 0; h < HALVES; ++h) {
-    {
-      float bias[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) bias[i] = e.b1[h * 128 + ch0 + i];
-      float4v acc_h[8][2];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        acc_h[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
-        acc_h[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
-      }
-      load_wfrags(wb, w2p + (size_t)h * 4 * 512);  // this half's W2 steps fly during the first GEMM
-      gemm_k128<false, 8>(acc_h, wa, xn, l15, q4);
-      if (h + 1 < HALVES) load_wfrags(wa, w1p + (size_t)(h + 1) * 4 * 512);  // next W1 block flies during the second GEMM
-      if (h > 0) __syncthreads();  // the previous half's second GEMM has finished reading the hidden tile
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = acc_h[t][0][j];
-          v[4 + j] = acc_h[t][1][j];
-        }
-        if (e.act == kActReLU) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752f));
-        }
-        *reinterpret_cast<short8*>(hh + (t * 16 + l15) * kStride + wave * 64 + q4 * 16) =
-            pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-      }
-    }
-    __syncthreads();
-    gemm_k128<false, 8>(acc_o, wb, hh, l15, q4);
-  }
-  unsigned short* og = e.attn.out + (size_t)b * HW * kD;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    int r = t * 16 + l15;
-    asm volatile("" : "+v"(r));
-    if (r < HW) *reinterpret_cast<short8*>(og + (size_t)r * kD + ch0) = pack8(acc_o[t][0], acc_o[t][1]);
-  }
+  ffn_tail<HALVES>(acc_o, xn, hh, HW, e.w1, e.b1, e.w2, e.b2, e.ln2_g, e.ln2_b, e.ln2_eps, e.act,
+                   e.attn.out + (size_t)b * HW * kD);
 }
 
 namespace {
@@ -873,6 +889,77 @@ __global__ __launch_bounds__(256, 3) void proj_rows_kernel(ProjRowsArgs a) {
   }
 }
 
+// Output projection + residual + the whole FFN half for 128-row tiles of the flat row space (any token count):
+// z = y + W2 act(W1 LN2(y)), y = x + att Wo + bo.  proj_rows_kernel + ffn_block_kernel in one launch: y never goes to
+// memory (one store and two loads of the activation tensor less per layer).
+struct ProjFfnRowsArgs {
+  const unsigned short* att;  // [rows, 128] attention output
+  const unsigned short* x;    // [rows, 128] layer input (residual)
+  const unsigned short* wo;   // packed 128 -> 128
+  const float* bo;
+  const unsigned short* w1;
+  const float* b1;
+  const unsigned short* w2;
+  const float* b2;
+  const float* ln2_g;
+  const float* ln2_b;
+  unsigned short* out;        // [rows, 128]
+  int rows, act;
+  float ln2_eps;
+};
+
+template <int HALVES>
+__global__ __launch_bounds__(256, 2) void proj_ffn_rows_kernel(ProjFfnRowsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xn = smem;
+  unsigned char* hh = smem + kTileBytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int row0 = blockIdx.x * kRows;
+  const int nrows = min(kRows, a.rows - row0);
+  const int ch0 = wave * 32 + q4 * 8;
+  WFrags w;
+  load_wfrags(w, reinterpret_cast<const short8*>(a.wo) + (size_t)wave * 128 + lane);
+  ResFrags res;
+  load_residual(res, a.x + (size_t)row0 * kD + ch0, nrows, l15);
+  stage_tile(a.att + (size_t)row0 * kD, hh, nrows, tid);
+  // rows >= nrows of the y tile are GEMM padding: keep them finite
+  for (int c = tid + nrows * 16; c < kRows * 16; c += 256) *reinterpret_cast<uint4*>(xn + (c >> 4) * kStride + (c & 15) * 16) = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  float bias[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bias[i] = a.bo[ch0 + i];
+  float4v y[8][2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    y[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
+    y[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
+  }
+  gemm_k128<false, 8>(y, w, hh, l15, q4);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      y[t][0][j] += bf16_to_float((unsigned short)res.r[t][j]);
+      y[t][1][j] += bf16_to_float((unsigned short)res.r[t][4 + j]);
+    }
+  }
+  ffn_tail<HALVES>(y, xn, hh, nrows, a.w1, a.b1, a.w2, a.b2, a.ln2_g, a.ln2_b, a.ln2_eps, a.act, a.out + (size_t)row0 * kD);
+}
+
+namespace {
+template <int HALVES>
+int launch_proj_ffn(const ProjFfnRowsArgs& a, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)proj_ffn_rows_kernel<HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
+    attr = true;
+  }
+  hipLaunchKernelGGL(proj_ffn_rows_kernel<HALVES>, dim3((a.rows + kRows - 1) / kRows), dim3(256), 2 * kTileBytes, stream, a);
+  return (int)hipGetLastError();
+}
+}  // namespace
+
 extern "C" {
 
 static int attn_block_impl(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
@@ -980,6 +1067,42 @@ int atri_attn_rows(const void* x, void* out, const void* wqkv, const float* bqkv
   ProjRowsArgs pa{(const unsigned short*)att, (const unsigned short*)x, (const unsigned short*)wo, bo, (unsigned short*)out, rows};
   hipLaunchKernelGGL(proj_rows_kernel, dim3(blocks), dim3(256), kFfnTileBytes, stream, pa);
   return (int)hipGetLastError();
+}
+
+// Whole encoder layer for up to 256 tokens (d_model 128, 4 heads, HW % 4 == 0) in three launches:
+// qkv_rows -> attn_core -> proj_ffn_rows.  Scratch buffers as in atri_attn_rows; x and out may not alias.
+int atri_layer_rows(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                    const float* ln1_g, const float* ln1_b, float ln1_eps, const void* w1, const float* b1, const void* w2,
+                    const float* b2, const float* ln2_g, const float* ln2_b, float ln2_eps, void* q, void* k, void* vt,
+                    void* att, int B, int HW, int D, int heads, int F, int act, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (D != kD || heads != 4 || HW < 1 || HW > 256 || (HW & 3) != 0) return -10;
+  if ((F & 127) != 0 || F < 128 || F > 512) return -12;
+  if (act != kActReLU && act != kActGELU) return -11;
+  if (x == out) return -13;
+  const int rows = B * HW;
+  const int blocks = (rows + kFfnRows - 1) / kFfnRows;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)qkv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnTileBytes);
+    attr = true;
+  }
+  QkvRowsArgs qa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, ln1_g, ln1_b, (unsigned short*)q,
+                 (unsigned short*)k, (unsigned short*)vt, rows, HW, ln1_eps};
+  hipLaunchKernelGGL(qkv_rows_kernel, dim3(blocks), dim3(256), kFfnTileBytes, stream, qa);
+  AttnCoreArgs ca{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)vt, (unsigned short*)att, B, HW};
+  if (HW <= 128) hipLaunchKernelGGL(attn_core_kernel<8>, dim3(B), dim3(256), 0, stream, ca);
+  else hipLaunchKernelGGL(attn_core_kernel<16>, dim3(B), dim3(256), 0, stream, ca);
+  ProjFfnRowsArgs pa{(const unsigned short*)att, (const unsigned short*)x, (const unsigned short*)wo, bo,
+                     (const unsigned short*)w1, b1, (const unsigned short*)w2, b2, ln2_g, ln2_b, (unsigned short*)out,
+                     rows, act, ln2_eps};
+  switch (F >> 7) {
+    case 1: return launch_proj_ffn<1>(pa, stream);
+    case 2: return launch_proj_ffn<2>(pa, stream);
+    case 3: return launch_proj_ffn<3>(pa, stream);
+    case 4: return launch_proj_ffn<4>(pa, stream);
+    default: return -12;
+  }
 }
 
 }  // extern "C"

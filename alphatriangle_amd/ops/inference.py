@@ -17,7 +17,8 @@ Layer -> kernel map (default config, B leaves, HW = 120 tokens):
   1x1 projections, QKV, out-proj, FFN    tile_gemm_kernel taps=1  (+LayerNorm prologue,
                                          residual / activation / positional epilogue)
   4-head attention                       attention_kernel         (MFMA, softmax in registers)
-  encoder layer, d_model 128, 129..256 tok qkv_rows_kernel + attn_core_kernel + proj_rows_kernel + ffn_block_kernel
+  encoder layer, d_model 128, 129..256 tok qkv_rows_kernel + attn_core_kernel + proj_ffn_rows_kernel (out-projection and FFN
+                                         half in one launch; also as proj_rows_kernel + ffn_block_kernel)
   encoder layer, d_model 128 / <=128 tok encoder_layer_kernel (tf_kernels.hip: one launch per layer, the residual stream
                                          stays in registers between the attention and FFN halves); the two halves
                                          also exist as attn_block_kernel + ffn_block_kernel
@@ -538,6 +539,15 @@ class InferenceEngine:
                             hb.f32(ff1.ln_eps), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads), hb.i32(ff1.cout),
                             hb.i32(self.act))
                     x = q
+                    continue
+                if self.rows_attn and self.fused_ffn and self.fuse_layer and self.act in (1, 2):
+                    # 129..256 tokens: QKV rows -> attention core -> (out-proj + FFN) rows; bufs[x] -> bufs[y]
+                    hb.call("atri_layer_rows", hb.ptr(bufs[x]), hb.ptr(bufs[y]), hb.ptr(qkv.w), hb.ptr(qkv.bias), hb.ptr(out.w),
+                            hb.ptr(out.bias), hb.ptr(qkv.ln_g), hb.ptr(qkv.ln_b), hb.f32(qkv.ln_eps), hb.ptr(ff1.w), hb.ptr(ff1.bias),
+                            hb.ptr(ff2.w), hb.ptr(ff2.bias), hb.ptr(ff1.ln_g), hb.ptr(ff1.ln_b), hb.f32(ff1.ln_eps), hb.ptr(bufs[q]),
+                            hb.ptr(bufs[t]), hb.ptr(self.vt), hb.ptr(bufs[h]), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads),
+                            hb.i32(ff1.cout), hb.i32(self.act))
+                    x = y
                     continue
                 # ---- attention half: bufs[x] -> bufs[y]
                 if self.fused_tf:

@@ -423,6 +423,38 @@ def test_one_launch_encoder_layer_matches_two_kernel_path_and_torch(act, rows, c
     assert (v1 - ref_v).abs().max().item() < 0.25
 
 
+def test_row_tiled_projection_ffn_kernel_matches_separate_kernels():
+    """12x21 board (252 tokens, 8 layers): proj_ffn_rows_kernel against proj_rows_kernel + ffn_block_kernel, and the
+    fp32 PyTorch module as the reference for both."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(14)
+    dev = _dev()
+    env, mc = EnvConfig.large(), ModelConfig.large_transformer()
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev)
+    eng = net.engine
+    assert eng is not None and eng.rows_attn and eng.fused_ffn and eng.fuse_layer
+    batch = 9
+    grid = torch.randint(-1, 2, (batch, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(batch, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    l1, v1 = (t.clone() for t in eng.forward(grid, other))
+    eng.fuse_layer = False
+    try:
+        l2, v2 = (t.clone() for t in eng.forward(grid, other))
+    finally:
+        eng.fuse_layer = True
+    torch.cuda.synchronize()
+    assert (l1 - l2).abs().max().item() < 0.08, (l1 - l2).abs().max().item()
+    assert (v1 - v2).abs().max().item() < 0.15
+    net.model.eval()
+    with torch.no_grad():
+        pl, vl = net.model(grid, other)
+    ref_v = (torch.softmax(vl.float(), 1) * net.support.to(dev)).sum(1)
+    err_fused, err_split = (l1 - pl).abs().max().item(), (l2 - pl).abs().max().item()
+    assert err_fused < max(0.25, 1.5 * err_split), (err_fused, err_split)
+    assert (v1 - ref_v).abs().max().item() < 0.4
+
+
 @pytest.mark.parametrize("hw", [252, 120, 64])
 def test_rows_attention_path_matches_torch(hw):
     """qkv_rows + attn_core + proj_rows (+ ffn_block) vs nn.TransformerEncoderLayer(norm_first=True) in fp32."""
