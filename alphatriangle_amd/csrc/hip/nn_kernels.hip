@@ -500,12 +500,13 @@ __global__ __launch_bounds__(256, 2) void fc_splitk_kernel(const unsigned short*
 
 // Shared FC fed directly by the body's NHWC rows (128 channels per pixel): the flatten is free (a sample's
 // rows are contiguous), the final LayerNorm - when there is one - is applied to each 128-wide pixel row while
-// it is staged into LDS (16 lanes per row, statistics by xor-shuffles), and the "other" features come from a
-// small bf16 side buffer as the last K steps.  Replaces rows_to_fc + fc_splitk and their 2 x 126 MB round trip.
+// it is staged into LDS (16 lanes per row, statistics by xor-shuffles), and the "other" features are read from the
+// caller's f32 rows as the last K steps.  Replaces rows_to_fc + fc_splitk and their 2 x 126 MB round trip.
 // steps_per_split is a multiple of 4, so every staged chunk of 4 K-steps is exactly one pixel row.
 template <int MT>
 __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned short* __restrict__ rows /*[B][HW][128]*/,
-                                                                const unsigned short* __restrict__ other /*[B][other_pad]*/,
+                                                                const float* __restrict__ other /*[B][other_dim] f32*/,
+                                                                int other_dim,
                                                                 const float* __restrict__ g, const float* __restrict__ bt,
                                                                 float eps, const unsigned short* __restrict__ Wp,
                                                                 float* __restrict__ slabs, int B, int HW, int other_pad,
@@ -545,8 +546,12 @@ __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned s
       if (s0 < s_end && b0 + r < B) {
         if (s0 < feat_steps) {
           v[i] = *reinterpret_cast<const uint4*>(rows + ((size_t)(b0 + r) * HW + (s0 >> 2)) * 128 + cc * 8);
-        } else if ((s0 - feat_steps) * 32 + cc * 8 < other_pad) {
-          v[i] = *reinterpret_cast<const uint4*>(other + (size_t)(b0 + r) * other_pad + (s0 - feat_steps) * 32 + cc * 8);
+        } else {  // the "other" features: converted from the caller's f32 rows on the fly (zero padded to other_pad)
+          const int d0 = (s0 - feat_steps) * 32 + cc * 8;
+          float f[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = d0 + j < other_dim ? other[(size_t)(b0 + r) * other_dim + d0 + j] : 0.f;
+          v[i] = __builtin_bit_cast(uint4, pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]));
         }
       }
     }
@@ -822,20 +827,20 @@ int atri_fc_splitk(const void* X, const void* Wp, float* slabs, int B, int Kp, i
 
 // Fused flatten (+ final LayerNorm) + shared FC for bodies with 128 channels per pixel.  SK splits of
 // steps_per_split K-steps each (a multiple of 4); slabs is [SK][B][128] f32.
-int atri_fc_rows_splitk(const void* rows, const void* other, const float* g, const float* bt, float eps, const void* Wp,
-                        float* slabs, int B, int HW, int D, int other_pad, int N, int SK, int steps_per_split,
+int atri_fc_rows_splitk(const void* rows, const float* other, int other_dim, const float* g, const float* bt, float eps,
+                        const void* Wp, float* slabs, int B, int HW, int D, int other_pad, int N, int SK, int steps_per_split,
                         hipStream_t stream) {
   if (B <= 0) return 0;
-  if (D != 128 || (other_pad & 31) != 0 || N > 128 || (N & 31) != 0) return -10;
+  if (D != 128 || (other_pad & 31) != 0 || other_dim < 0 || other_dim > other_pad || N > 128 || (N & 31) != 0) return -10;
   if ((steps_per_split & 3) != 0 || steps_per_split <= 0) return -11;
   if ((long long)SK * steps_per_split < (long long)HW * 4 + (other_pad >> 5)) return -12;
   if (B >= 2048)  // enough samples to fill the chip with 128-sample workgroups
     hipLaunchKernelGGL(fc_rows_splitk_kernel<8>, dim3((B + 127) / 128, SK), dim3(256), 0, stream, (const unsigned short*)rows,
-                       (const unsigned short*)other, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
+                       other, other_dim, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
                        steps_per_split);
   else
     hipLaunchKernelGGL(fc_rows_splitk_kernel<4>, dim3((B + 63) / 64, SK), dim3(256), 0, stream, (const unsigned short*)rows,
-                       (const unsigned short*)other, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
+                       other, other_dim, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
                        steps_per_split);
   return hip_err(hipGetLastError());
 }

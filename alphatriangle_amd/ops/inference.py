@@ -401,7 +401,6 @@ class InferenceEngine:
         maxc = max(widths)
         self.bufs = [torch.empty(rows * maxc, dtype=torch.bfloat16, device=dev) for _ in range(5)]
         self.fc_in = None if self.fc_fused else torch.zeros(batch, self.fc_kp, dtype=torch.bfloat16, device=dev)
-        self.other_bf16 = torch.zeros(batch, self.other_pad, dtype=torch.bfloat16, device=dev)
         self.vt = torch.zeros(batch * 4 * 32 * 256, dtype=torch.bfloat16, device=dev) if self.rows_attn else None
         self.slabs = torch.empty(self.fc_sk, batch, 128, dtype=torch.float32, device=dev)
         dense_w = max([self.fc_n] + [l.cout for l in self.shared_rest + self.policy_layers + self.value_layers])
@@ -576,10 +575,8 @@ class InferenceEngine:
         else:
             ln = None
         if self.fc_fused:
-            hb.call("atri_other_to_fc", hb.ptr(other), hb.ptr(self.other_bf16), hb.i32(B), hb.i32(self.other_dim),
-                    hb.i32(self.other_pad), hb.i32(self.other_pad), hb.i32(0))
             g, bt, eps = ln if ln is not None else (None, None, 0.0)
-            hb.call("atri_fc_rows_splitk", hb.ptr(bufs[cur]), hb.ptr(self.other_bf16), hb.ptr(g), hb.ptr(bt), hb.f32(eps),
+            hb.call("atri_fc_rows_splitk", hb.ptr(bufs[cur]), hb.ptr(other), hb.i32(self.other_dim), hb.ptr(g), hb.ptr(bt), hb.f32(eps),
                     hb.ptr(self.fc_w), hb.ptr(self.slabs), hb.i32(B), hb.i32(self.HW), hb.i32(self.feat_c), hb.i32(self.other_pad),
                     hb.i32(self.fc_n), hb.i32(self.fc_sk), hb.i32(self.fc_steps_per_split))
         else:
