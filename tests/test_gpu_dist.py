@@ -49,7 +49,7 @@ print("collectives ok", flush=True)
 # a data-parallel learner step: all-reduce of the flat gradient buffer between backward and the update,
 # issued from a side stream as the overlapped loop does
 env, mc = EnvConfig(), ModelConfig()
-tc = TrainConfig(DEVICE="cuda", BATCH_SIZE=32, MAX_TRAINING_STEPS=10)
+tc = TrainConfig(DEVICE="cuda", BATCH_SIZE=32, MAX_TRAINING_STEPS=10, COMPILE_MODEL=True)
 net = NeuralNetwork(mc, env, tc, dev)
 calls = []
 def grad_sync(flat):
@@ -67,6 +67,15 @@ with torch.cuda.stream(side):
 torch.cuda.current_stream(dev).wait_stream(side)
 torch.cuda.synchronize()
 assert calls == [tr.flat.total] and torch.isfinite(info["total_loss"]) and not torch.equal(before, tr.flat.flat_param)
+# the first step captured forward/backward into a HIP graph while the process group (and its watchdog thread) was
+# alive; further steps replay it with the eager all-reduce in between
+assert tr.graph_report.get("replayed") is True and tr.graph_report["memset_nodes"] == 0, tr.graph_report
+for _ in range(3):
+    with torch.cuda.stream(side):
+        info, td = tr.train_step_tensors(tb)
+    torch.cuda.synchronize()
+    assert torch.isfinite(info["total_loss"]) and torch.isfinite(tr.flat.flat_param).all()
+assert len(calls) == 4
 wire = WeightWire(net._orig_model)
 buf = wire.pack()
 ctx.broadcast_weights(buf)
