@@ -49,6 +49,28 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return v;
 }
 
+// Maximum over the four lanes that share (lane & 15): lane, lane ^ 16, lane ^ 32, lane ^ 48.  gfx950's row-swap
+// instructions exchange whole 16-lane rows between two registers in one VALU operation
+// (v_permlane16_swap: odd rows of the first operand <-> even rows of the second; v_permlane32_swap: upper half of
+// the first <-> lower half of the second), so with both operands equal the pair holds each lane's own value and
+// its partner's.  __shfl_xor goes through ds_bpermute instead, an LDS round trip per exchange.
+__device__ __forceinline__ float quad_row_max(float m) {
+  const unsigned u = __float_as_uint(m);
+  const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float a = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+  const unsigned v = __float_as_uint(a);
+  const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+}
+__device__ __forceinline__ float quad_row_sum(float m) {
+  const unsigned u = __float_as_uint(m);
+  const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float a = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+  const unsigned v = __float_as_uint(a);
+  const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+
 enum Act : int { kActNone = 0, kActReLU = 1, kActGELU = 2, kActSiLU = 3, kActTanh = 4, kActSigmoid = 5 };
 
 __device__ __forceinline__ float apply_act(float x, int act) {

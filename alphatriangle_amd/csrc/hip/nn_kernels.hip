@@ -340,8 +340,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const unsigned short* __
           m = fmaxf(m, st[kt][j]);
         }
       }
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = quad_row_max(m);
       float sum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
@@ -351,8 +350,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const unsigned short* __
           st[kt][j] = p;
           sum += p;
         }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = quad_row_sum(sum);
       const float inv = 1.0f / sum;
       float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -283,8 +283,7 @@ __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char*
 #pragma unroll
       for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = quad_row_max(m);
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
@@ -798,8 +797,7 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnCoreArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = quad_row_max(m);
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
