@@ -193,7 +193,9 @@ struct AttnBlockArgs {
 // Attention half of the layer for sample b: leaves y = x + OutProj(MHA(LayerNorm1(x))) in registers, lane layout
 // y[t][n][j] = channel wave*32 + q4*8 + n*4 + j of token t*16 + l15 (rows >= HW hold finite padding values).
 // On return every wave is past its last read of the xn tile; the ao tile may still be read by other waves.
-template <int DBG>
+// FULL8: the token count is known to lie in (112, 128], i.e. eight query tiles and only the last key tile partly
+// padded; the tile loop and the padding masks then carry no run-time branches.
+template <int DBG, bool FULL8 = false>
 __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char* xn, unsigned char* ao, int b,
                                           float4v (&y)[8][2]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -263,8 +265,8 @@ __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char*
   }
   load_wfrags(wb, reinterpret_cast<const short8*>(a.wo) + (size_t)wave * 128 + lane);  // out-proj weights fly during attention
   // ---- attention of head `wave`, one 16-query tile at a time
-  const int n_qt = (DBG & 4) ? 0 : (HW + 15) >> 4;
-  const int kt_full = HW >> 4;  // key tiles below this index hold no padding
+  const int n_qt = (DBG & 4) ? 0 : (FULL8 ? 8 : (HW + 15) >> 4);
+  const int kt_full = FULL8 ? 7 : HW >> 4;  // key tiles below this index hold no padding
   const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
 #pragma unroll
   for (int qt = 0; qt < 8; ++qt) {
@@ -299,7 +301,7 @@ __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char*
       o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][1], pf, o1, 0, 0, 0);
       os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
     }
-    const float inv = 1.0f / os[0];
+    const float inv = __builtin_amdgcn_rcpf(os[0]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       o0[j] *= inv;
@@ -582,7 +584,7 @@ struct EncoderLayerArgs {
   float ln2_eps;
 };
 
-template <int HALVES>
+template <int HALVES, bool FULL8>
 __global__ __launch_bounds__(256, 2) void encoder_layer_kernel(EncoderLayerArgs e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xn = smem;
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void encoder_layer_kernel(EncoderLayerArgs 
   const int HW = e.attn.HW;
   const int ch0 = wave * 32 + q4 * 8;
   float4v acc_o[8][2];
-  attn_body<0>(e.attn, xn, hh, b, acc_o);
+  attn_body<0, FULL8>(e.attn, xn, hh, b, acc_o);
 
   ffn_tail<HALVES>(acc_o, xn, hh, HW, e.w1, e.b1, e.w2, e.b2, e.ln2_g, e.ln2_b, e.ln2_eps, e.act,
                    e.attn.out + (size_t)b * HW * kD);
@@ -622,15 +624,19 @@ int launch_ffn(const FfnBlockArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL((ffn_block_kernel<HALVES, TILES>), dim3((a.rows + rows_wg - 1) / rows_wg), dim3(256), lds, stream, a);
   return (int)hipGetLastError();
 }
-template <int HALVES>
-int launch_layer(const EncoderLayerArgs& e, hipStream_t stream) {
+template <int HALVES, bool FULL8>
+int launch_layer_inst(const EncoderLayerArgs& e, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)encoder_layer_kernel<HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
+    (void)hipFuncSetAttribute((const void*)encoder_layer_kernel<HALVES, FULL8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
     attr = true;
   }
-  hipLaunchKernelGGL(encoder_layer_kernel<HALVES>, dim3(e.attn.B), dim3(256), 2 * kTileBytes, stream, e);
+  hipLaunchKernelGGL((encoder_layer_kernel<HALVES, FULL8>), dim3(e.attn.B), dim3(256), 2 * kTileBytes, stream, e);
   return (int)hipGetLastError();
+}
+template <int HALVES>
+int launch_layer(const EncoderLayerArgs& e, hipStream_t stream) {
+  return e.attn.HW > 112 ? launch_layer_inst<HALVES, true>(e, stream) : launch_layer_inst<HALVES, false>(e, stream);
 }
 }  // namespace
 
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnCoreArgs a) {
       o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][1], pf, o1, 0, 0, 0);
       os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
     }
-    const float inv = 1.0f / os[0];
+    const float inv = __builtin_amdgcn_rcpf(os[0]);
     // lane holds dims 4q4..4q4+3 (o0) and 16+4q4..+3 (o1) of query qt*16 + l15
     if (qt * 16 + l15 < HW) {
       uint2 lo, hi;
