@@ -757,7 +757,9 @@ struct AttnCoreArgs {
   int B, HW;
 };
 
-template <int NKT>
+// KTF >= 0: the first key tile that holds padding is known at compile time (token count in (16 KTF, 16 KTF + 16]),
+// so the padding masks cost no run-time branches; KTF < 0 derives it from the token count.
+template <int NKT, int KTF = -1>
 __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnCoreArgs a) {
   const int lane = threadIdx.x & 63, head = threadIdx.x >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
@@ -785,11 +787,15 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnCoreArgs a) {
     }
   const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const int n_qt = (HW + 15) >> 4;
-  const int kt_full = HW >> 4;
+  const int kt_full = KTF >= 0 ? KTF : HW >> 4;
   unsigned short* ob_ = a.out + (size_t)b * HW * kD + head * 32 + q4 * 4;
+  short8 Qnext = *reinterpret_cast<const short8*>(qb_ + (size_t)min(l15, HW - 1) * kD);
   for (int qt = 0; qt < n_qt; ++qt) {
-    const int qtok = min(qt * 16 + l15, HW - 1);
-    const short8 Qf = *reinterpret_cast<const short8*>(qb_ + (size_t)qtok * kD);
+    const short8 Qf = Qnext;
+    {  // next query tile: requested a whole tile ahead (the last iteration re-reads a valid row)
+      const int qtok = min((qt + 1) * 16 + l15, HW - 1);
+      Qnext = *reinterpret_cast<const short8*>(qb_ + (size_t)qtok * kD);
+    }
     float4v st[NKT];
     float m = -1e30f;
 #pragma unroll
@@ -952,6 +958,16 @@ __global__ __launch_bounds__(256, 2) void proj_ffn_rows_kernel(ProjFfnRowsArgs a
 }
 
 namespace {
+void launch_attn_core(const AttnCoreArgs& ca, hipStream_t stream) {
+  const int HW = ca.HW;
+  if (HW > 240) hipLaunchKernelGGL((attn_core_kernel<16, 15>), dim3(ca.B), dim3(256), 0, stream, ca);
+  else if (HW > 128) hipLaunchKernelGGL((attn_core_kernel<16, -1>), dim3(ca.B), dim3(256), 0, stream, ca);
+  else if (HW > 112) hipLaunchKernelGGL((attn_core_kernel<8, 7>), dim3(ca.B), dim3(256), 0, stream, ca);
+  else hipLaunchKernelGGL((attn_core_kernel<8, -1>), dim3(ca.B), dim3(256), 0, stream, ca);
+}
+}  // namespace
+
+namespace {
 template <int HALVES>
 int launch_proj_ffn(const ProjFfnRowsArgs& a, hipStream_t stream) {
   static bool attr = false;
@@ -1066,8 +1082,7 @@ int atri_attn_rows(const void* x, void* out, const void* wqkv, const float* bqkv
                  (unsigned short*)k, (unsigned short*)vt, rows, HW, ln_eps};
   hipLaunchKernelGGL(qkv_rows_kernel, dim3(blocks), dim3(256), kFfnTileBytes, stream, qa);
   AttnCoreArgs ca{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)vt, (unsigned short*)att, B, HW};
-  if (HW <= 128) hipLaunchKernelGGL(attn_core_kernel<8>, dim3(B), dim3(256), 0, stream, ca);
-  else hipLaunchKernelGGL(attn_core_kernel<16>, dim3(B), dim3(256), 0, stream, ca);
+  launch_attn_core(ca, stream);
   ProjRowsArgs pa{(const unsigned short*)att, (const unsigned short*)x, (const unsigned short*)wo, bo, (unsigned short*)out, rows};
   hipLaunchKernelGGL(proj_rows_kernel, dim3(blocks), dim3(256), kFfnTileBytes, stream, pa);
   return (int)hipGetLastError();
@@ -1095,8 +1110,7 @@ int atri_layer_rows(const void* x, void* out, const void* wqkv, const float* bqk
                  (unsigned short*)k, (unsigned short*)vt, rows, HW, ln1_eps};
   hipLaunchKernelGGL(qkv_rows_kernel, dim3(blocks), dim3(256), kFfnTileBytes, stream, qa);
   AttnCoreArgs ca{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)vt, (unsigned short*)att, B, HW};
-  if (HW <= 128) hipLaunchKernelGGL(attn_core_kernel<8>, dim3(B), dim3(256), 0, stream, ca);
-  else hipLaunchKernelGGL(attn_core_kernel<16>, dim3(B), dim3(256), 0, stream, ca);
+  launch_attn_core(ca, stream);
   ProjFfnRowsArgs pa{(const unsigned short*)att, (const unsigned short*)x, (const unsigned short*)wo, bo,
                      (const unsigned short*)w1, b1, (const unsigned short*)w2, b2, ln2_g, ln2_b, (unsigned short*)out,
                      rows, act, ln2_eps};
