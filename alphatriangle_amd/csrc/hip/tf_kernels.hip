@@ -333,14 +333,14 @@ __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char*
   }
 }
 
-template <int DBG>
+template <int DBG, bool FULL8>
 __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x;
   float4v y[8][2];
-  attn_body<DBG>(a, smem, smem + kTileBytes, b, y);
+  attn_body<DBG, FULL8>(a, smem, smem + kTileBytes, b, y);
   const int ch0 = wave * 32 + q4 * 8;
   unsigned short* og = a.out + (size_t)b * a.HW * kD;
 #pragma unroll
@@ -602,15 +602,22 @@ __global__ __launch_bounds__(256, 2) void encoder_layer_kernel(EncoderLayerArgs 
 }
 
 namespace {
-template <int DBG>
-int launch_attn(const AttnBlockArgs& a, hipStream_t stream) {
+template <int DBG, bool FULL8>
+int launch_attn_inst(const AttnBlockArgs& a, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_block_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
+    (void)hipFuncSetAttribute((const void*)attn_block_kernel<DBG, FULL8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
     attr = true;
   }
-  hipLaunchKernelGGL(attn_block_kernel<DBG>, dim3(a.B), dim3(256), 2 * kTileBytes, stream, a);
+  hipLaunchKernelGGL((attn_block_kernel<DBG, FULL8>), dim3(a.B), dim3(256), 2 * kTileBytes, stream, a);
   return (int)hipGetLastError();
+}
+// Probe variants (DBG != 0) exist for the 113..128-token specialisation only.
+template <int DBG>
+int launch_attn(const AttnBlockArgs& a, hipStream_t stream) {
+  if (a.HW > 112) return launch_attn_inst<DBG, true>(a, stream);
+  if (DBG != 0) return -14;
+  return launch_attn_inst<0, false>(a, stream);
 }
 
 template <int HALVES, int TILES = kFfnBlockTiles>
