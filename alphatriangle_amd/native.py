@@ -9,6 +9,7 @@ missing, so that GPU code paths cannot silently fall back to eager PyTorch.
 from __future__ import annotations
 
 import ctypes
+import os
 import importlib
 import threading
 from pathlib import Path
@@ -42,7 +43,9 @@ def host() -> ModuleType:
 
 
 def hip_library_path() -> Path:
-    return _PKG / "libatri_hip.so"
+    """The in-tree kernel library; ``ATRI_HIP_LIB`` names another build of it (same-box A/B runs of kernel variants)."""
+    override = os.environ.get("ATRI_HIP_LIB")
+    return Path(override) if override else _PKG / "libatri_hip.so"
 
 
 def hip_available() -> bool:
