@@ -443,23 +443,29 @@ __global__ __launch_bounds__(256, (TILES <= 4 ? 3 : 2)) void ffn_block_kernel(Ff
       gemm_k128<false, TILES>(acc_h, wa, yn, l15, q4);
       if (h + 1 < halves) load_wfrags(wa, w1p + (size_t)(h + 1) * 4 * 512);  // next W1 block flies during the second GEMM
       if (h > 0) __syncthreads();  // the previous half's second GEMM has finished reading the hidden tile
+      // one activation branch per half, not per tile: the ReLU path is then straight-line code between the two GEMMs
+      if (a.act == kActReLU) {
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) {
-        float v[8];
+        for (int t = 0; t < TILES; ++t) {
+          float4v lo = acc_h[t][0], hi = acc_h[t][1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = acc_h[t][0][j];
-          v[4 + j] = acc_h[t][1][j];
+          for (int j = 0; j < 4; ++j) {
+            lo[j] = fmaxf(lo[j], 0.f);
+            hi[j] = fmaxf(hi[j], 0.f);
+          }
+          *reinterpret_cast<short8*>(hh + (t * 16 + l15) * kStride + wave * 64 + q4 * 16) = pack8(lo, hi);
         }
-        if (a.act == kActReLU) {
+      } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-        } else {
+        for (int t = 0; t < TILES; ++t) {
+          float4v lo = acc_h[t][0], hi = acc_h[t][1];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752f));
+          for (int j = 0; j < 4; ++j) {
+            lo[j] = 0.5f * lo[j] * (1.0f + erff(lo[j] * 0.70710678118654752f));
+            hi[j] = 0.5f * hi[j] * (1.0f + erff(hi[j] * 0.70710678118654752f));
+          }
+          *reinterpret_cast<short8*>(hh + (t * 16 + l15) * kStride + wave * 64 + q4 * 16) = pack8(lo, hi);
         }
-        *reinterpret_cast<short8*>(hh + (t * 16 + l15) * kStride + wave * 64 + q4 * 16) =
-            pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
       }
     }
     __syncthreads();
@@ -538,23 +544,29 @@ __device__ __forceinline__ void ffn_tail(float4v (&acc_o)[8][2], unsigned char* 
       gemm_k128<false, 8>(acc_h, wa, xn, l15, q4);
       if (h + 1 < HALVES) load_wfrags(wa, w1p + (size_t)(h + 1) * 4 * 512);  // next W1 block flies during the second GEMM
       if (h > 0) __syncthreads();  // the previous half's second GEMM has finished reading the hidden tile
+      // one activation branch per half, not per tile: the ReLU path is then straight-line code between the two GEMMs
+      if (act == kActReLU) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        float v[8];
+        for (int t = 0; t < 8; ++t) {
+          float4v lo = acc_h[t][0], hi = acc_h[t][1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = acc_h[t][0][j];
-          v[4 + j] = acc_h[t][1][j];
+          for (int j = 0; j < 4; ++j) {
+            lo[j] = fmaxf(lo[j], 0.f);
+            hi[j] = fmaxf(hi[j], 0.f);
+          }
+          *reinterpret_cast<short8*>(hh + (t * 16 + l15) * kStride + wave * 64 + q4 * 16) = pack8(lo, hi);
         }
-        if (act == kActReLU) {
+      } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-        } else {
+        for (int t = 0; t < 8; ++t) {
+          float4v lo = acc_h[t][0], hi = acc_h[t][1];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752f));
+          for (int j = 0; j < 4; ++j) {
+            lo[j] = 0.5f * lo[j] * (1.0f + erff(lo[j] * 0.70710678118654752f));
+            hi[j] = 0.5f * hi[j] * (1.0f + erff(hi[j] * 0.70710678118654752f));
+          }
+          *reinterpret_cast<short8*>(hh + (t * 16 + l15) * kStride + wave * 64 + q4 * 16) = pack8(lo, hi);
         }
-        *reinterpret_cast<short8*>(hh + (t * 16 + l15) * kStride + wave * 64 + q4 * 16) =
-            pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
       }
     }
     __syncthreads();
