@@ -148,10 +148,14 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
     // board plane, first-layer weights and bias go to a side area of LDS, then every thread evaluates the
     // 3x3 single-channel conv for its (pixel, 8-channel) chunks straight into the halo tile
     float* aux = reinterpret_cast<float*>(smem + a.aux_off);
-    float* gplane = aux;                   // [HW]
-    float* wl = aux + 128;                 // [9][CIN]
+    float* gplane = aux;                   // [(H + 2) * (W + 2)] board plane with a zero border: taps need no bounds checks
+    float* wl = aux + 192;                 // [9][CIN]
     float* bl = wl + 9 * CIN;              // [CIN]
-    for (int i = tid; i < a.HW; i += 256) gplane[i] = a.grid[(size_t)b * a.HW + i];
+    const int PW = W + 2;
+    for (int i = tid; i < (H + 2) * PW; i += 256) {
+      const int yy = i / PW - 1, xx = i - (yy + 1) * PW - 1;
+      gplane[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? a.grid[(size_t)b * a.HW + yy * W + xx] : 0.f;
+    }
     for (int i = tid; i < 9 * CIN; i += 256) wl[i] = a.w_first[i];
     for (int i = tid; i < CIN; i += 256) bl[i] = a.b_first[i];
     __syncthreads();
@@ -164,13 +168,14 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = bl[cc * 8 + j];
+        const float* gp = gplane + y * PW + x;  // top-left tap of this pixel in the padded plane
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-          if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-          const float gv = gplane[yy * W + xx];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += gv * wl[tap * CIN + cc * 8 + j];
+          const float gv = gp[(tap / 3) * PW + tap % 3];
+          const float4* wq = reinterpret_cast<const float4*>(wl + tap * CIN + cc * 8);
+          const float4 w0 = wq[0], w1 = wq[1];
+          v[0] += gv * w0.x; v[1] += gv * w0.y; v[2] += gv * w0.z; v[3] += gv * w0.w;
+          v[4] += gv * w1.x; v[5] += gv * w1.y; v[6] += gv * w1.z; v[7] += gv * w1.w;
         }
         if (a.first_act == kActReLU) {
 #pragma unroll
@@ -449,7 +454,7 @@ int atri_rowconv_first(const float* grid, const float* w_first, const float* b_f
   a.out_off = (n_blocks > 1) ? in_bytes : 0;
   int lds = (n_blocks > 1) ? in_bytes + out_bytes : (in_bytes > out_bytes ? in_bytes : out_bytes);
   a.aux_off = (lds + 15) & ~15;              // board plane + first-layer weights live behind the tiles
-  lds = a.aux_off + (128 + 10 * Cin) * 4;
+  lds = a.aux_off + (192 + 10 * Cin) * 4;
   a.ymagic = 65536 / W + 1;
   for (int p = 0; p < a.HW; ++p)
     if (((p * a.ymagic) >> 16) != p / W) return -12;
@@ -526,7 +531,7 @@ int atri_rowconv_stem(const float* grid, const float* w_first, const float* b_fi
   a.out_off = 0;  // the output staging tile reuses both input tiles once the last main loop is done
   int lds = a.tile2_off + tile2 > out_bytes ? a.tile2_off + tile2 : out_bytes;
   a.aux_off = (lds + 15) & ~15;
-  lds = a.aux_off + (128 + 10 * C0) * 4;
+  lds = a.aux_off + (192 + 10 * C0) * 4;
   a.ymagic = 65536 / W + 1;
   for (int p = 0; p < a.HW; ++p)
     if (((p * a.ymagic) >> 16) != p / W) return -12;
