@@ -117,7 +117,8 @@ __device__ __forceinline__ void rowconv_mainloop(float4v (&acc)[8][2], const uns
 }  // namespace
 
 // DBG != 0 instantiations are roofline probes (bench/conv_probe.py), bit mask: 1 no LDS fragment reads,
-// 2 no weight-fragment loads, 4 no main loop, 16 no input staging loads, 32 no write-back phase.
+// 2 no weight-fragment loads, 4 no main loop, 16 no input staging loads, 32 no write-back phase, 64 no first-layer
+// evaluation while staging (FIRST instantiations).
 // FIRST: the input tile is not read from memory but computed from the raw board (first conv layer, Cin_first = 1),
 // which removes a separate memory-bound kernel and the round trip of its output.
 // PAIR: a whole residual block (alphatriangle/nn/model.py:40-59) per launch.  The first convolution's activated
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
       const int r = c / CPR, cc = c - r * CPR;
       const int rr = r - 17, y = rr >> 4, x = rr & 15;
       short8 o = (short8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (rr >= 0 && y < H && x < W) {
+      if (!(DBG & 64) && rr >= 0 && y < H && x < W) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = bl[cc * 8 + j];
@@ -501,9 +502,9 @@ int atri_rowconv_pair(const void* in, const void* w1, const float* b1, const voi
 // Conv stem in one launch: board plane -> conv(1 -> C0) -> conv(C0 -> C1) -> conv(C1 -> C2), every layer followed by
 // the activation; only the last layer's output goes to memory.  (C0, C1, C2) = (32, 64, 128).
 // w_first [9][C0] / b_first [C0]: first layer (evaluated while staging); (w1, b1), (w2, b2): packed second and third layer.
-int atri_rowconv_stem(const float* grid, const float* w_first, const float* b_first, const void* w1, const float* b1,
-                      const void* w2, const float* b2, const float* post_add, void* out, int B, int H, int W, int C0, int C1,
-                      int C2, int act, hipStream_t stream) {
+static int rowconv_stem_impl(const float* grid, const float* w_first, const float* b_first, const void* w1, const float* b1,
+                             const void* w2, const float* b2, const float* post_add, void* out, int B, int H, int W, int C0,
+                             int C1, int C2, int act, int dbg, hipStream_t stream) {
   if (B <= 0) return 0;
   if (C0 != 32 || C1 != 64 || C2 != 128 || !atri_rowconv_supported(H, W, C0, C1) || H * W > 128) return -10;
   RowConvArgs a{};
@@ -535,7 +536,28 @@ int atri_rowconv_stem(const float* grid, const float* w_first, const float* b_fi
   a.ymagic = 65536 / W + 1;
   for (int p = 0; p < a.HW; ++p)
     if (((p * a.ymagic) >> 16) != p / W) return -12;
-  return launch_rowconv_inst<32, 0, true, true, 64>(a, lds, stream);
+  switch (dbg) {
+    case 0: return launch_rowconv_inst<32, 0, true, true, 64>(a, lds, stream);
+    case 4: return launch_rowconv_inst<32, 4, true, true, 64>(a, lds, stream);
+    case 32: return launch_rowconv_inst<32, 32, true, true, 64>(a, lds, stream);
+    case 36: return launch_rowconv_inst<32, 36, true, true, 64>(a, lds, stream);
+    case 64: return launch_rowconv_inst<32, 64, true, true, 64>(a, lds, stream);
+    case 100: return launch_rowconv_inst<32, 100, true, true, 64>(a, lds, stream);
+    default: return -14;
+  }
+}
+
+int atri_rowconv_stem(const float* grid, const float* w_first, const float* b_first, const void* w1, const float* b1,
+                      const void* w2, const float* b2, const float* post_add, void* out, int B, int H, int W, int C0, int C1,
+                      int C2, int act, hipStream_t stream) {
+  return rowconv_stem_impl(grid, w_first, b_first, w1, b1, w2, b2, post_add, out, B, H, W, C0, C1, C2, act, 0, stream);
+}
+
+// Roofline probe of the conv stem (see the kernel's DBG parameter; 100 = 4 + 32 + 64: launch, tile zeroing and barriers only).
+int atri_rowconv_stem_probe(const float* grid, const float* w_first, const float* b_first, const void* w1, const float* b1,
+                            const void* w2, const float* b2, void* out, int B, int H, int W, int act, int dbg,
+                            hipStream_t stream) {
+  return rowconv_stem_impl(grid, w_first, b_first, w1, b1, w2, b2, nullptr, out, B, H, W, 32, 64, 128, act, dbg, stream);
 }
 
 // Roofline probe: the same launch with ingredients removed (see the kernel's DBG parameter).
