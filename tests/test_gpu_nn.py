@@ -498,3 +498,69 @@ def test_rows_attention_path_matches_torch(hw):
     zerr = (z.float() - ref_z).abs().max().item()
     assert yerr < 0.06, f"attention half err {yerr}"
     assert zerr < 0.08, f"layer err {zerr}"
+
+
+_ODD_CONFIGS = {
+    "silu_no_bn_cnn": dict(ACTIVATION_FUNCTION="SiLU", USE_BATCH_NORM=False, USE_TRANSFORMER=False),
+    "tanh_cnn": dict(ACTIVATION_FUNCTION="Tanh", USE_TRANSFORMER=False),
+    "gelu_no_bn": dict(ACTIVATION_FUNCTION="GELU", USE_BATCH_NORM=False),
+    "narrow_transformer": dict(TRANSFORMER_DIM=64, TRANSFORMER_HEADS=2, TRANSFORMER_FC_DIM=128),
+    "wide_ffn": dict(TRANSFORMER_FC_DIM=512, TRANSFORMER_LAYERS=1),
+    "no_res_blocks": dict(NUM_RESIDUAL_BLOCKS=0),
+    "one_res_block_64": dict(NUM_RESIDUAL_BLOCKS=1, RESIDUAL_BLOCK_FILTERS=64),
+    "small_stem": dict(CONV_FILTERS=[32, 64], CONV_KERNEL_SIZES=[3, 3], CONV_STRIDES=[1, 1], CONV_PADDING=[1, 1],
+                       RESIDUAL_BLOCK_FILTERS=64, TRANSFORMER_DIM=64, TRANSFORMER_HEADS=2, TRANSFORMER_FC_DIM=64),
+    "deep_heads": dict(FC_DIMS_SHARED=[128, 64], POLICY_HEAD_DIMS=[64, 64], VALUE_HEAD_DIMS=[32], NUM_VALUE_ATOMS=21),
+    "cnn_gelu": dict(USE_TRANSFORMER=False, ACTIVATION_FUNCTION="GELU"),
+}
+
+
+def test_unsupported_widths_fall_back_to_the_pytorch_module():
+    """Widths the kernels do not tile (not a power of two, below 32) switch the engine off with a reason; evaluation
+    then runs the PyTorch module."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.ops.inference import engine_supports
+
+    env = EnvConfig()
+    mc = ModelConfig(NUM_RESIDUAL_BLOCKS=1, RESIDUAL_BLOCK_FILTERS=96, TRANSFORMER_DIM=96, TRANSFORMER_HEADS=4)
+    ok, why = engine_supports(mc, env)
+    assert not ok and "96" in why
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), _dev())
+    assert net.engine is None
+    grid = torch.zeros(3, 1, env.ROWS, env.COLS, device=_dev())
+    other = torch.zeros(3, mc.OTHER_NN_INPUT_FEATURES_DIM, device=_dev())
+    logits, value = net.evaluate_features(grid, other)
+    assert logits.shape == (3, env.ACTION_DIM) and value.shape[0] == 3 and torch.isfinite(logits).all()
+
+
+@pytest.mark.parametrize("name", sorted(_ODD_CONFIGS))
+def test_engine_matches_pytorch_on_unusual_configurations(name):
+    """Configurations away from the default make the engine leave its specialised kernels (one-launch stem / block /
+    layer / tail) for the generic ones; whatever mix it picks has to reproduce the fp32 PyTorch module."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(21)
+    dev = _dev()
+    env = EnvConfig()
+    mc = ModelConfig(**_ODD_CONFIGS[name])
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev)
+    with torch.no_grad():
+        for m in net.model.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.7, 1.3)
+    net.sync_inference_weights()
+    eng = net.engine
+    assert eng is not None
+    batch = 11
+    grid = torch.randint(-1, 2, (batch, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(batch, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    logits, value = (t.clone() for t in eng.forward(grid, other))
+    net.model.eval()
+    with torch.no_grad():
+        pl, vl = net.model(grid, other)
+    ref_v = (torch.softmax(vl.float(), 1) * net.support.to(dev)).sum(1)
+    scale = max(1.0, pl.abs().max().item())
+    assert torch.isfinite(logits).all() and torch.isfinite(value).all()
+    assert (logits - pl).abs().max().item() < 0.06 * scale + 0.1, (name, (logits - pl).abs().max().item(), scale)
+    assert (value - ref_v).abs().max().item() < 0.3, (name, (value - ref_v).abs().max().item())
