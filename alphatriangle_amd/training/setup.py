@@ -87,6 +87,10 @@ def setup_training_components(
         neural_net = NeuralNetwork(model_config, env_config, train_config, device)
 
         use_gpu_engine = system_config.ENGINE == "gpu" or (system_config.ENGINE == "auto" and device.type == "cuda")
+        if use_gpu_engine and system_config.ENGINE == "auto" and neural_net.engine is None:
+            # a model the HIP kernels do not tile (see ops/inference.py: engine_supports): host workers + PyTorch network
+            logger.warning("SystemConfig.ENGINE='auto': no HIP inference engine for this model config; using host self-play workers.")
+            use_gpu_engine = False
         split = dist_context is not None and not dist_context.layout.colocated
         pure_actor = split and not dist_context.is_learner
         pure_learner = split and not dist_context.is_actor
