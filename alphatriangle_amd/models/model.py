@@ -168,6 +168,52 @@ def _linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | Non
     return y.view(*lead, weight.shape[0])
 
 
+class _LayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last dimension through the learner's HIP kernels (``ops.hip_learner.layer_norm_*``).
+
+    Rows keep their dtype: under autocast the bf16 activations are normalised with fp32 statistics and come out as
+    bf16, where torch's autocast policy would run the op in fp32 between two cast kernels.
+    """
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:  # noqa: ANN001
+        from ..ops import hip_learner
+
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        w32, b32 = weight.float().contiguous(), bias.float().contiguous()
+        y, mean, rstd = hip_learner.layer_norm_forward(x2, w32, b32, eps)
+        ctx.save_for_backward(x2, w32, mean, rstd)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        x2, w32, mean, rstd = ctx.saved_tensors
+        dy2 = grad_out.reshape(x2.shape).to(x2.dtype).contiguous()
+        dx, dg, db = hip_learner.layer_norm_backward(x2, dy2, w32, mean, rstd)
+        return dx.view(ctx.shape), dg, db, None
+
+
+class FastLayerNorm(nn.LayerNorm):
+    """``nn.LayerNorm`` (same parameters, same ``state_dict`` keys) whose GPU path is :class:`_LayerNormFn`."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if (
+            x.is_cuda and self.elementwise_affine and self.bias is not None and len(self.normalized_shape) == 1
+            and self.normalized_shape[0] in (64, 128, 256, 512) and x.dtype in (torch.bfloat16, torch.float32)
+        ):
+            return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+    @classmethod
+    def adopt(cls, norm: nn.LayerNorm) -> "FastLayerNorm":
+        """Re-class an existing ``nn.LayerNorm`` (keeps its parameters)."""
+        norm.__class__ = cls
+        return norm  # type: ignore[return-value]
+
+
 class EncoderLayer(nn.TransformerEncoderLayer):
     """``nn.TransformerEncoderLayer`` (same sub-modules, same ``state_dict`` keys) with a learner fast path.
 
@@ -177,6 +223,11 @@ class EncoderLayer(nn.TransformerEncoderLayer):
     (``x + drop(attn(norm1(x)))``, then ``x + drop(ffn(norm2(x)))``).  Everything else falls back to the stock
     implementation.
     """
+
+    def __init__(self, *args, **kwargs):  # noqa: ANN002, ANN003
+        super().__init__(*args, **kwargs)
+        FastLayerNorm.adopt(self.norm1)
+        FastLayerNorm.adopt(self.norm2)
 
     def _fast_ok(self, src: torch.Tensor, src_mask, src_key_padding_mask, is_causal: bool) -> bool:  # noqa: ANN001
         attn = self.self_attn
@@ -343,7 +394,7 @@ class AlphaTriangleNet(nn.Module):
                 norm_first=True,
             )
             self.transformer_body = nn.TransformerEncoder(
-                layer, num_layers=mc.TRANSFORMER_LAYERS, norm=nn.LayerNorm(d), enable_nested_tensor=False
+                layer, num_layers=mc.TRANSFORMER_LAYERS, norm=FastLayerNorm(d), enable_nested_tensor=False
             )
             self.transformer_output_size = self.body_hw[0] * self.body_hw[1] * d
             feat = self.transformer_output_size

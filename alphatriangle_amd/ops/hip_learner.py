@@ -102,6 +102,34 @@ def colsum(g: torch.Tensor) -> torch.Tensor:
     return out
 
 
+LN_WIDTHS = (64, 128, 256, 512)
+
+
+def layer_norm_forward(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``y, mean, rstd`` of LayerNorm over the last dimension of a contiguous ``[rows, D]`` bf16 / fp32 matrix."""
+    rows, d = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    hb.call("atri_ln_fwd", hb.ptr(x2), hb.i32(1 if x2.dtype == torch.bfloat16 else 0), hb.ptr(weight), hb.ptr(bias), hb.ptr(y),
+            hb.ptr(mean), hb.ptr(rstd), hb.i32(rows), hb.i32(d), hb.f32(eps))
+    return y, mean, rstd
+
+
+def layer_norm_backward(x2: torch.Tensor, dy2: torch.Tensor, weight: torch.Tensor, mean: torch.Tensor,
+                        rstd: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``dx [rows, D]`` (dtype of x), ``dgamma [D]``, ``dbeta [D]`` (fp32)."""
+    rows, d = x2.shape
+    rows_per_block = 512 if rows >= 8192 else 64
+    blocks = (rows + rows_per_block - 1) // rows_per_block
+    dx = torch.empty_like(x2)
+    partial = torch.empty(blocks * 2 * d, dtype=torch.float32, device=x2.device)
+    dgb = torch.empty(2 * d, dtype=torch.float32, device=x2.device)
+    hb.call("atri_ln_bwd", hb.ptr(x2), hb.ptr(dy2), hb.i32(1 if x2.dtype == torch.bfloat16 else 0), hb.ptr(weight), hb.ptr(mean),
+            hb.ptr(rstd), hb.ptr(dx), hb.ptr(partial), hb.ptr(dgb), hb.ptr(dgb[d:]), hb.i32(rows), hb.i32(d), hb.i32(rows_per_block))
+    return dx, dgb[:d], dgb[d:]
+
+
 # ---------------------------------------------------------------- prioritized replay tree
 def per_set_leaves(tree: torch.Tensor, P: int, idx: torch.Tensor, count: torch.Tensor | None, count_max: int, prio: torch.Tensor) -> None:
     hb.call("atri_per_set_leaves", hb.ptr(tree), hb.i64(P), hb.ptr(idx), hb.ptr(count), hb.i32(count_max), hb.ptr(prio))

@@ -217,3 +217,30 @@ def test_colsum_kernel_matches_fp32_sum(n, f, dtype):
     out = hip_learner.colsum(g)
     assert out.dtype == torch.float32 and out.shape == (f,)
     assert torch.allclose(out, ref, rtol=1e-4, atol=1e-3 * (n ** 0.5))
+
+
+@pytest.mark.parametrize("rows,d,dtype", [(30720, 128, torch.bfloat16), (1000, 128, torch.float32), (777, 64, torch.bfloat16),
+                                            (130, 256, torch.float32), (65, 512, torch.bfloat16)])
+def test_layer_norm_kernels_match_torch(rows, d, dtype):
+    """Forward and backward of the learner's LayerNorm kernels against torch's fp32 LayerNorm on the same (rounded) input."""
+    from alphatriangle_amd.models.model import FastLayerNorm
+
+    torch.manual_seed(rows + d)
+    dev = torch.device("cuda")
+    ln = FastLayerNorm(d).to(dev)
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.3)
+        ln.bias.normal_(0.0, 0.3)
+    x = (torch.randn(rows, d, device=dev) * 2.0 + 0.5).to(dtype).requires_grad_(True)
+    gy = torch.randn(rows, d, device=dev).to(dtype)
+    y = ln(x)
+    assert y.dtype == dtype and y.shape == x.shape
+    gx, gw, gb = torch.autograd.grad(y, [x, ln.weight, ln.bias], gy)
+    xr = x.detach().float().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (d,), ln.weight.float(), ln.bias.float(), ln.eps)
+    gxr, gwr, gbr = torch.autograd.grad(yr, [xr, ln.weight, ln.bias], gy.float())
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    assert (y.float() - yr).abs().max().item() < tol * max(1.0, yr.abs().max().item())
+    assert (gx.float() - gxr).abs().max().item() < tol * max(1.0, gxr.abs().max().item())
+    assert torch.allclose(gw.float(), gwr, rtol=1e-3, atol=1e-3 * rows ** 0.5)
+    assert torch.allclose(gb.float(), gbr, rtol=1e-3, atol=1e-3 * rows ** 0.5)
