@@ -20,6 +20,12 @@ from ..config.env_config import EnvConfig
 from ..config.model_config import ModelConfig
 
 
+def _grad_dtype(partial: torch.Tensor) -> torch.dtype:
+    """Weight gradients of half-precision GEMMs are summed straight into fp32 (the parameters' dtype under autocast),
+    which saves the cast kernel autograd would otherwise append."""
+    return torch.float32 if partial.dtype in (torch.bfloat16, torch.float16) else partial.dtype
+
+
 def _split_count(n: int, limit: int = 32, min_chunk: int = 512) -> int:
     """Largest divisor of ``n`` that is at most ``limit`` and leaves chunks of at least ``min_chunk``."""
     for s in range(min(limit, max(1, n // min_chunk)), 1, -1):
@@ -82,7 +88,7 @@ class _ConvGemm(torch.autograd.Function):
             g2 = grad_out.permute(1, 0, 2, 3).reshape(cout, n)
             s = _split_count(n)
             parts = torch.bmm(g2.view(cout, s, n // s).transpose(0, 1), cols.view(k, s, n // s).permute(1, 2, 0))
-            d_w = (parts.sum(0) if s > 1 else parts[0]).view(cout, cin, kh, kw)
+            d_w = parts.sum(0, dtype=_grad_dtype(parts)).view(cout, cin, kh, kw)
         if ctx.needs_input_grad[0]:
             g_cols = _patch_matrix(grad_out, kh, kw, kh - 1 - ph, kw - 1 - pw)  # [Cout*kh*kw, B*H*W]
             w_t = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * kh * kw)
@@ -149,13 +155,14 @@ class _SplitKLinear(torch.autograd.Function):
         d_x = g @ weight if ctx.needs_input_grad[0] else None
         d_w = None
         if ctx.needs_input_grad[1]:
-            d_w = torch.bmm(gs.transpose(1, 2), x2.reshape(s, n // s, x2.shape[1])).sum(0)
+            parts = torch.bmm(gs.transpose(1, 2), x2.reshape(s, n // s, x2.shape[1]))
+            d_w = parts.sum(0, dtype=_grad_dtype(parts))
         d_b = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if g.is_cuda and g.dtype in (torch.bfloat16, torch.float32):
                 from ..ops import hip_learner  # torch's multi-block column sum records a memset node under capture
 
-                d_b = hip_learner.colsum(g).to(g.dtype)
+                d_b = hip_learner.colsum(g)  # fp32, like the parameter
             else:
                 d_b = gs.sum(1).sum(0)
         return d_x, d_w, d_b

@@ -120,7 +120,7 @@ def layer_norm_backward(x2: torch.Tensor, dy2: torch.Tensor, weight: torch.Tenso
                         rstd: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``dx [rows, D]`` (dtype of x), ``dgamma [D]``, ``dbeta [D]`` (fp32)."""
     rows, d = x2.shape
-    rows_per_block = 512 if rows >= 8192 else 64
+    rows_per_block = max(32, (rows + 511) // 512 + 31 & ~31)  # about 500 workgroups, whole 32-row passes
     blocks = (rows + rows_per_block - 1) // rows_per_block
     dx = torch.empty_like(x2)
     partial = torch.empty(blocks * 2 * d, dtype=torch.float32, device=x2.device)
