@@ -856,6 +856,190 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnCoreArgs a) {
   }
 }
 
+// LayerNorm1 + QKV projection + attention core of one (sample, head pair) per workgroup, for 129..256 tokens:
+// Q, K and V never go to memory.  Eight waves: wave (hh, quarter) owns head 2*pair + hh and the 64 tokens of its
+// quarter.  It loads those rows straight into MFMA operand registers (no LDS tile), normalises them in registers
+// (LayerNorm's affine part is folded into the weights by the host), and produces Q (kept), K and V^T of its tokens.
+// The K / V^T operand images go through LDS lane-linearly - producer and consumer lanes hold identical fragments,
+// so the exchange is a conflict-free register dump of 64 KB - and after one barrier every wave holds the K and
+// V^T fragments of all 256 key slots of its head and runs its four query tiles exactly like attn_core_kernel.
+struct QkvAttnArgs {
+  const unsigned short* x;     // [B, HW, 128]
+  const unsigned short* wqkv;  // packed, LayerNorm affine folded in, Q pre-scaled by log2(e)/sqrt(32)
+  const float* bqkv;           // [384]
+  unsigned short* att;         // [B, HW, 128]
+  int B, HW;
+  float ln_eps;
+};
+constexpr int kQkvAttnLds = 2 * (16 + 16) * 1024;
+
+template <bool SWAP, int MT>
+__device__ __forceinline__ void gemm_regs(float4v (&acc)[MT][2], const WFrags& w, const short8 (&xf)[MT][4]) {
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      if (SWAP) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t][kc], w.f[kc][0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t][kc], w.f[kc][1], acc[t][1], 0, 0, 0);
+      } else {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f[kc][0], xf[t][kc], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f[kc][1], xf[t][kc], acc[t][1], 0, 0, 0);
+      }
+    }
+}
+
+// KTF as in attn_core_kernel: index of the first key tile that holds padding when known at compile time, else -1.
+// The wave's 64 tokens go through the projections in two passes of 32 (the weight fragments are re-read from L1 / L2),
+// and the attention loop reads its K / V^T fragments from LDS at every use: under 128 VGPRs, so two workgroups
+// (16 waves) share a CU and fill each other's MFMA -> softmax -> MFMA dependency stalls.
+template <int KTF>
+__global__ __launch_bounds__(512, 4) void qkv_attn_kernel(QkvAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = wave >> 2, quarter = wave & 3;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  // workgroups blk and blk + 8 land on the same XCD (hence the same L2) and share a sample
+  const int blk = blockIdx.x;
+  const int pair = (blk >> 3) & 1;
+  const int b = (blk >> 4) * 8 + (blk & 7);
+  if (b >= a.B) return;  // uniform over the workgroup, ahead of the barrier
+  const int head = pair * 2 + hh;
+  const int HW = a.HW;
+  const unsigned short* xg = a.x + (size_t)b * HW * kD;
+  const short8* wq = reinterpret_cast<const short8*>(a.wqkv) + (size_t)head * 128 + lane;
+  short8* kimg = reinterpret_cast<short8*>(smem) + (size_t)hh * 16 * 64 + lane;               // [2][16 kt][64]
+  short8* vimg = reinterpret_cast<short8*>(smem + 32 * 1024) + (size_t)hh * 16 * 64 + lane;  // [2][8 kb][2 n][64]
+
+  short8 Qf[4];
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp) {
+    WFrags w;
+    load_wfrags(w, wq + (size_t)4 * 512);  // K weights
+    short8 xf[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int tok = min(quarter * 64 + (tp * 2 + t) * 16 + l15, HW - 1);  // padding rows repeat the last token (finite, masked as keys)
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) xf[t][kc] = *reinterpret_cast<const short8*>(xg + (size_t)tok * kD + kc * 32 + q4 * 8);
+    }
+    // LayerNorm in registers: a token's 128 channels sit in the four lanes that share l15, 32 values each
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = bf16_to_float((unsigned short)xf[t][kc][j]);
+          s += v;
+          ss += v * v;
+        }
+      s = quad_row_sum(s);
+      ss = quad_row_sum(ss);
+      const float mean = s * (1.0f / kD);
+      const float rstd = rsqrtf(fmaxf(ss * (1.0f / kD) - mean * mean, 0.f) + a.ln_eps);
+      const float shift = -mean * rstd;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = bf16_to_float((unsigned short)xf[t][kc][j]) * rstd + shift;
+        xf[t][kc] = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+      }
+    }
+    {  // ---- K of these 32 tokens -> LDS image
+      float bias[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[kD + head * 32 + q4 * 8 + i];
+      float4v acc[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
+        acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
+      }
+      gemm_regs<false, 2>(acc, w, xf);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) kimg[(quarter * 4 + tp * 2 + t) * 64] = pack8(acc[t][0], acc[t][1]);
+    }
+    load_wfrags(w, wq + (size_t)8 * 512);  // V weights
+    {  // ---- V with swapped operands: acc[t][n][j] = V[token t*16 + 4 q4 + j][dim perm(l15, n)] -> V^T operand images
+      const int chp = (l15 >> 2) * 8 + (l15 & 3);
+      const float bv0 = a.bqkv[2 * kD + head * 32 + chp], bv1 = a.bqkv[2 * kD + head * 32 + chp + 4];
+      float4v acc[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t][0] = (float4v){bv0, bv0, bv0, bv0};
+        acc[t][1] = (float4v){bv1, bv1, bv1, bv1};
+      }
+      gemm_regs<true, 2>(acc, w, xf);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) vimg[((quarter * 2 + tp) * 2 + n) * 64] = pack8(acc[0][n], acc[1][n]);
+    }
+    load_wfrags(w, wq);  // Q weights
+    {  // ---- Q of these 32 tokens stays in registers
+      float bias[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[head * 32 + q4 * 8 + i];
+      float4v acc[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
+        acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
+      }
+      gemm_regs<false, 2>(acc, w, xf);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) Qf[tp * 2 + t] = pack8(acc[t][0], acc[t][1]);
+    }
+  }
+  __syncthreads();
+
+  const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
+  const int kt_full = KTF >= 0 ? KTF : HW >> 4;  // key tiles below this index hold no padding
+  unsigned short* og = a.att + (size_t)b * HW * kD + head * 32 + q4 * 8;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int q0 = quarter * 64 + t * 16;
+    if (q0 >= HW) break;  // wave-uniform
+    __builtin_amdgcn_sched_barrier(0);  // keep query tiles from interleaving: each holds 64 score registers
+    float4v st[16];
+    float m = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+      st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg[kt * 64], Qf[t], (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      if (kt >= kt_full) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
+    }
+    m = quad_row_max(m);
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st[kt][j] = __builtin_amdgcn_exp2f(st[kt][j] - m);  // scores arrive in log2 units
+    // O^T = V^T P^T; a ones fragment as a third "V^T" tile yields the softmax denominators from the same MFMA pass
+    float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f}, os = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      const short8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vimg[(kb * 2 + 0) * 64], pf, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vimg[(kb * 2 + 1) * 64], pf, o1, 0, 0, 0);
+      os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
+    }
+    const float inv = __builtin_amdgcn_rcpf(os[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o0[j] *= inv;
+      o1[j] *= inv;
+    }
+    // lane holds channels head*32 + q4*8 .. +7 of query q0 + l15
+    if (q0 + l15 < HW) *reinterpret_cast<short8*>(og + (size_t)(q0 + l15) * kD) = pack8(o0, o1);
+  }
+}
+
 struct ProjRowsArgs {
   const unsigned short* in;        // [rows, 128] attention output
   const unsigned short* residual;  // [rows, 128]
@@ -1107,12 +1291,10 @@ int atri_attn_rows(const void* x, void* out, const void* wqkv, const float* bqkv
   return (int)hipGetLastError();
 }
 
-// Whole encoder layer for up to 256 tokens (d_model 128, 4 heads, HW % 4 == 0) in three launches:
-// qkv_rows -> attn_core -> proj_ffn_rows.  Scratch buffers as in atri_attn_rows; x and out may not alias.
-int atri_layer_rows(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
-                    const float* ln1_g, const float* ln1_b, float ln1_eps, const void* w1, const float* b1, const void* w2,
-                    const float* b2, const float* ln2_g, const float* ln2_b, float ln2_eps, void* q, void* k, void* vt,
-                    void* att, int B, int HW, int D, int heads, int F, int act, hipStream_t stream) {
+static int layer_rows_impl(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                           const float* ln1_g, const float* ln1_b, float ln1_eps, const void* w1, const float* b1, const void* w2,
+                           const float* b2, const float* ln2_g, const float* ln2_b, float ln2_eps, void* q, void* k, void* vt,
+                           void* att, int B, int HW, int D, int heads, int F, int act, bool fused_qkv, hipStream_t stream) {
   if (B <= 0) return 0;
   if (D != kD || heads != 4 || HW < 1 || HW > 256 || (HW & 3) != 0) return -10;
   if ((F & 127) != 0 || F < 128 || F > 512) return -12;
@@ -1125,11 +1307,25 @@ int atri_layer_rows(const void* x, void* out, const void* wqkv, const float* bqk
     (void)hipFuncSetAttribute((const void*)qkv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnTileBytes);
     attr = true;
   }
-  QkvRowsArgs qa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, ln1_g, ln1_b, (unsigned short*)q,
-                 (unsigned short*)k, (unsigned short*)vt, rows, HW, ln1_eps};
-  hipLaunchKernelGGL(qkv_rows_kernel, dim3(blocks), dim3(256), kFfnTileBytes, stream, qa);
-  AttnCoreArgs ca{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)vt, (unsigned short*)att, B, HW};
-  launch_attn_core(ca, stream);
+  if (ln1_g == nullptr && ln1_b == nullptr && HW > 128 && fused_qkv) {
+    // LayerNorm1 + QKV + attention in one launch per layer: Q, K and V stay on the chip
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute((const void*)qkv_attn_kernel<15>, hipFuncAttributeMaxDynamicSharedMemorySize, kQkvAttnLds);
+      (void)hipFuncSetAttribute((const void*)qkv_attn_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, kQkvAttnLds);
+      attr2 = true;
+    }
+    QkvAttnArgs fa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, (unsigned short*)att, B, HW, ln1_eps};
+    const int wgs = ((B + 7) / 8) * 16;
+    if (HW > 240) hipLaunchKernelGGL(qkv_attn_kernel<15>, dim3(wgs), dim3(512), kQkvAttnLds, stream, fa);
+    else hipLaunchKernelGGL(qkv_attn_kernel<-1>, dim3(wgs), dim3(512), kQkvAttnLds, stream, fa);
+  } else {
+    QkvRowsArgs qa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, ln1_g, ln1_b, (unsigned short*)q,
+                   (unsigned short*)k, (unsigned short*)vt, rows, HW, ln1_eps};
+    hipLaunchKernelGGL(qkv_rows_kernel, dim3(blocks), dim3(256), kFfnTileBytes, stream, qa);
+    AttnCoreArgs ca{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)vt, (unsigned short*)att, B, HW};
+    launch_attn_core(ca, stream);
+  }
   ProjFfnRowsArgs pa{(const unsigned short*)att, (const unsigned short*)x, (const unsigned short*)wo, bo,
                      (const unsigned short*)w1, b1, (const unsigned short*)w2, b2, ln2_g, ln2_b, (unsigned short*)out,
                      rows, act, ln2_eps};
@@ -1140,6 +1336,28 @@ int atri_layer_rows(const void* x, void* out, const void* wqkv, const float* bqk
     case 4: return launch_proj_ffn<4>(pa, stream);
     default: return -12;
   }
+}
+
+// Whole encoder layer for 129..256 tokens (d_model 128, 4 heads, HW % 4 == 0), x and out may not alias.  Two launches
+// when LayerNorm1's affine part is folded into wqkv (ln1_g == ln1_b == nullptr): qkv_attn -> proj_ffn_rows, with
+// att [B*HW, 128] the only scratch that is touched; otherwise three: qkv_rows -> attn_core -> proj_ffn_rows with
+// q, k [B*HW, 128] and vt [B, 4, 32, 256] (zero-filled once) as further scratch.
+int atri_layer_rows(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                    const float* ln1_g, const float* ln1_b, float ln1_eps, const void* w1, const float* b1, const void* w2,
+                    const float* b2, const float* ln2_g, const float* ln2_b, float ln2_eps, void* q, void* k, void* vt,
+                    void* att, int B, int HW, int D, int heads, int F, int act, hipStream_t stream) {
+  return layer_rows_impl(x, out, wqkv, bqkv, wo, bo, ln1_g, ln1_b, ln1_eps, w1, b1, w2, b2, ln2_g, ln2_b, ln2_eps, q, k, vt,
+                         att, B, HW, D, heads, F, act, true, stream);
+}
+
+// The three-launch form regardless of folding (comparison baseline for tests and benchmarks).
+int atri_layer_rows_unfused(const void* x, void* out, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                            const float* ln1_g, const float* ln1_b, float ln1_eps, const void* w1, const float* b1,
+                            const void* w2, const float* b2, const float* ln2_g, const float* ln2_b, float ln2_eps, void* q,
+                            void* k, void* vt, void* att, int B, int HW, int D, int heads, int F, int act,
+                            hipStream_t stream) {
+  return layer_rows_impl(x, out, wqkv, bqkv, wo, bo, ln1_g, ln1_b, ln1_eps, w1, b1, w2, b2, ln2_g, ln2_b, ln2_eps, q, k, vt,
+                         att, B, HW, D, heads, F, act, false, stream);
 }
 
 }  // extern "C"

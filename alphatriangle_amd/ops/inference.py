@@ -34,6 +34,7 @@ from __future__ import annotations
 
 import logging
 import math
+import os
 from dataclasses import dataclass
 from typing import Any
 
@@ -231,6 +232,7 @@ class InferenceEngine:
         self.use_rowconv = True  # tests flip this to cover the generic tile kernel on small boards
         self.fuse_res_blocks = True  # tests flip this to compare the fused residual-block kernel with two launches
         self.fuse_stem = True  # tests flip this to compare the one-launch conv stem with per-layer launches
+        self.tf_chunk = int(os.environ.get("ATRI_TF_CHUNK", "0"))  # samples per pass of the 129..256-token layer stack (0 = whole batch)
         self.fuse_layer = True  # tests flip this to compare the one-launch encoder layer with attn_block + ffn_block
         self.use_fused_heads = True  # tests flip this to compare the fused tail kernel with the per-layer launches
         self.heads_fused = False
@@ -526,7 +528,30 @@ class InferenceEngine:
                 cur = dst
             D, heads = self.mc.TRANSFORMER_DIM, self.mc.TRANSFORMER_HEADS
             x = cur
-            for tl in self.tf_layers:
+            rows_path = (
+                not self.fused_tf and self.rows_attn and self.fused_ffn and self.fuse_layer and self.act in (1, 2)
+            )
+            if rows_path:
+                # 129..256 tokens: QKV rows -> attention core -> (out-proj + FFN) rows per layer.  The batch goes through
+                # the whole layer stack in chunks whose q / k / v / attention scratch (one chunk's worth, shared by all
+                # chunks) stays in the 256 MB memory-side cache instead of streaming through HBM.
+                free = [i for i in range(5) if i != x]
+                src, dst, q, t, h = x, free[0], free[1], free[2], free[3]
+                chunk = self.tf_chunk if 0 < self.tf_chunk < B else B
+                for s0 in range(0, B, chunk):
+                    n = min(chunk, B - s0)
+                    off = s0 * self.HW * D
+                    a, b = src, dst
+                    for tl in self.tf_layers:
+                        qkv, out, ff1, ff2 = tl["qkv"], tl["out"], tl["ff1"], tl["ff2"]
+                        hb.call("atri_layer_rows", hb.ptr(bufs[a][off:]), hb.ptr(bufs[b][off:]), hb.ptr(qkv.w), hb.ptr(qkv.bias),
+                                hb.ptr(out.w), hb.ptr(out.bias), hb.ptr(qkv.ln_g), hb.ptr(qkv.ln_b), hb.f32(qkv.ln_eps),
+                                hb.ptr(ff1.w), hb.ptr(ff1.bias), hb.ptr(ff2.w), hb.ptr(ff2.bias), hb.ptr(ff1.ln_g), hb.ptr(ff1.ln_b),
+                                hb.f32(ff1.ln_eps), hb.ptr(bufs[q]), hb.ptr(bufs[t]), hb.ptr(self.vt), hb.ptr(bufs[h]), hb.i32(n),
+                                hb.i32(self.HW), hb.i32(D), hb.i32(heads), hb.i32(ff1.cout), hb.i32(self.act))
+                        a, b = b, a
+                x = src if len(self.tf_layers) % 2 == 0 else dst
+            for tl in (() if rows_path else self.tf_layers):
                 free = [i for i in range(5) if i != x]
                 q, t, y, h = free[0], free[1], free[2], free[3]
                 qkv, out, ff1, ff2 = tl["qkv"], tl["out"], tl["ff1"], tl["ff2"]
@@ -538,15 +563,6 @@ class InferenceEngine:
                             hb.f32(ff1.ln_eps), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads), hb.i32(ff1.cout),
                             hb.i32(self.act))
                     x = q
-                    continue
-                if self.rows_attn and self.fused_ffn and self.fuse_layer and self.act in (1, 2):
-                    # 129..256 tokens: QKV rows -> attention core -> (out-proj + FFN) rows; bufs[x] -> bufs[y]
-                    hb.call("atri_layer_rows", hb.ptr(bufs[x]), hb.ptr(bufs[y]), hb.ptr(qkv.w), hb.ptr(qkv.bias), hb.ptr(out.w),
-                            hb.ptr(out.bias), hb.ptr(qkv.ln_g), hb.ptr(qkv.ln_b), hb.f32(qkv.ln_eps), hb.ptr(ff1.w), hb.ptr(ff1.bias),
-                            hb.ptr(ff2.w), hb.ptr(ff2.bias), hb.ptr(ff1.ln_g), hb.ptr(ff1.ln_b), hb.f32(ff1.ln_eps), hb.ptr(bufs[q]),
-                            hb.ptr(bufs[t]), hb.ptr(self.vt), hb.ptr(bufs[h]), hb.i32(B), hb.i32(self.HW), hb.i32(D), hb.i32(heads),
-                            hb.i32(ff1.cout), hb.i32(self.act))
-                    x = y
                     continue
                 # ---- attention half: bufs[x] -> bufs[y]
                 if self.fused_tf:

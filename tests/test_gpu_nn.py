@@ -500,6 +500,59 @@ def test_rows_attention_path_matches_torch(hw):
     assert zerr < 0.08, f"layer err {zerr}"
 
 
+@pytest.mark.parametrize("hw,batch", [(252, 13), (256, 8), (200, 5), (132, 3)])
+def test_qkv_attention_one_launch_matches_three_launch_form_and_torch(hw, batch):
+    """qkv_attn_kernel (LayerNorm1 + QKV + attention per sample and head pair, Q / K / V never in memory) + proj_ffn_rows
+    against the qkv_rows -> attn_core -> proj_ffn_rows form and nn.TransformerEncoderLayer(norm_first=True) in fp32."""
+    from alphatriangle_amd.ops import hipbind as hb
+    from alphatriangle_amd.ops.inference import pack_gemm_weights
+
+    torch.manual_seed(hw + batch)
+    dev = _dev()
+    D, Fd, heads = 128, 256, 4
+    layer = torch.nn.TransformerEncoderLayer(D, heads, Fd, dropout=0.0, activation="relu", batch_first=True, norm_first=True).to(dev).eval()
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(_bf16_round(p + 0.05 * torch.randn_like(p)))
+    x = _bf16_round(torch.randn(batch, hw, D, device=dev) * 1.5 + 0.3)
+    with torch.no_grad():
+        ref = layer(x)
+
+    def pk(w_nk):
+        return pack_gemm_weights(w_nk.detach().float().t().unsqueeze(0).contiguous(), dev)[0]
+
+    g1, be1 = layer.norm1.weight.detach().float(), layer.norm1.bias.detach().float()
+    w_in = layer.self_attn.in_proj_weight.detach().float().clone()
+    b_in = layer.self_attn.in_proj_bias.detach().float().clone()
+    b_in = b_in + w_in @ be1  # LayerNorm1's affine part folded into the projection, as the engine does
+    w_in = w_in * g1[None, :]
+    w_in[:D] *= math.log2(math.e) / math.sqrt(32)
+    b_in[:D] *= math.log2(math.e) / math.sqrt(32)
+    b_in = b_in.contiguous()
+    xb = x.to(torch.bfloat16).contiguous()
+    q, k, att = torch.zeros_like(xb), torch.zeros_like(xb), torch.zeros_like(xb)
+    vt = torch.zeros(batch * 4 * 32 * 256, dtype=torch.bfloat16, device=dev)
+    w_qkv, w_o, w_1, w_2 = pk(w_in), pk(layer.self_attn.out_proj.weight), pk(layer.linear1.weight), pk(layer.linear2.weight)
+    b_o = layer.self_attn.out_proj.bias.detach().float().contiguous()
+    g2, be2 = layer.norm2.weight.detach().float().contiguous(), layer.norm2.bias.detach().float().contiguous()
+    b1, b2 = layer.linear1.bias.detach().float().contiguous(), layer.linear2.bias.detach().float().contiguous()
+    outs = {}
+    for name in ("atri_layer_rows", "atri_layer_rows_unfused"):
+        z = torch.full_like(xb, 7.0)
+        att.fill_(3.0)
+        hb.call(name, hb.ptr(xb), hb.ptr(z), hb.ptr(w_qkv), hb.ptr(b_in), hb.ptr(w_o), hb.ptr(b_o), hb.ptr(None), hb.ptr(None),
+                hb.f32(layer.norm1.eps), hb.ptr(w_1), hb.ptr(b1), hb.ptr(w_2), hb.ptr(b2), hb.ptr(g2), hb.ptr(be2),
+                hb.f32(layer.norm2.eps), hb.ptr(q), hb.ptr(k), hb.ptr(vt), hb.ptr(att), hb.i32(batch), hb.i32(hw), hb.i32(D),
+                hb.i32(heads), hb.i32(Fd), hb.i32(1))
+        torch.cuda.synchronize()
+        outs[name] = z.float()
+    e1 = (outs["atri_layer_rows"] - ref).abs().max().item()
+    e3 = (outs["atri_layer_rows_unfused"] - ref).abs().max().item()
+    assert e3 < 0.1, e3
+    assert e1 < max(0.1, 1.5 * e3), (e1, e3)
+    assert (outs["atri_layer_rows"] - outs["atri_layer_rows_unfused"]).abs().max().item() < 0.1
+
+
 _ODD_CONFIGS = {
     "silu_no_bn_cnn": dict(ACTIVATION_FUNCTION="SiLU", USE_BATCH_NORM=False, USE_TRANSFORMER=False),
     "tanh_cnn": dict(ACTIVATION_FUNCTION="Tanh", USE_TRANSFORMER=False),
