@@ -660,7 +660,9 @@ int launch_layer(const EncoderLayerArgs& e, hipStream_t stream) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------
-// Encoder attention for boards with more than 128 tokens (up to 256), d_model 128, 4 heads: three kernels.
+// Encoder attention for boards with more than 128 tokens (up to 256), d_model 128, 4 heads.  The production path is
+// qkv_attn_kernel further down (LayerNorm1 + QKV + attention in one launch); the three kernels here are the form
+// that keeps LayerNorm's affine parameters separate and writes Q / K / V^T to memory:
 //   qkv_rows_kernel  : token-wise LN1 + QKV projection over 64-row tiles of the flat row space.  Q and K are
 //                      written row-major; V is produced with swapped MFMA operands and written TRANSPOSED
 //                      ([sample][head][dim][token], token pitch 256) so that the attention core can load the

@@ -17,8 +17,9 @@ Layer -> kernel map (default config, B leaves, HW = 120 tokens):
   1x1 projections, QKV, out-proj, FFN    tile_gemm_kernel taps=1  (+LayerNorm prologue,
                                          residual / activation / positional epilogue)
   4-head attention                       attention_kernel         (MFMA, softmax in registers)
-  encoder layer, d_model 128, 129..256 tok qkv_rows_kernel + attn_core_kernel + proj_ffn_rows_kernel (out-projection and FFN
-                                         half in one launch; also as proj_rows_kernel + ffn_block_kernel)
+  encoder layer, d_model 128, 129..256 tok qkv_attn_kernel (LN1 + QKV + attention per sample and head pair, Q / K / V stay
+                                         on the chip) + proj_ffn_rows_kernel (out-projection and FFN half in one
+                                         launch); also as qkv_rows + attn_core + proj_rows + ffn_block kernels
   encoder layer, d_model 128 / <=128 tok encoder_layer_kernel (tf_kernels.hip: one launch per layer, the residual stream
                                          stays in registers between the attention and FFN halves); the two halves
                                          also exist as attn_block_kernel + ffn_block_kernel
@@ -34,7 +35,6 @@ from __future__ import annotations
 
 import logging
 import math
-import os
 from dataclasses import dataclass
 from typing import Any
 
@@ -232,7 +232,7 @@ class InferenceEngine:
         self.use_rowconv = True  # tests flip this to cover the generic tile kernel on small boards
         self.fuse_res_blocks = True  # tests flip this to compare the fused residual-block kernel with two launches
         self.fuse_stem = True  # tests flip this to compare the one-launch conv stem with per-layer launches
-        self.tf_chunk = int(os.environ.get("ATRI_TF_CHUNK", "0"))  # samples per pass of the 129..256-token layer stack (0 = whole batch)
+        self.tf_chunk = 0  # samples per pass of the 129..256-token layer stack (0 = whole batch; chunking measured no gain)
         self.fuse_layer = True  # tests flip this to compare the one-launch encoder layer with attn_block + ffn_block
         self.use_fused_heads = True  # tests flip this to compare the fused tail kernel with the per-layer launches
         self.heads_fused = False
@@ -532,9 +532,8 @@ class InferenceEngine:
                 not self.fused_tf and self.rows_attn and self.fused_ffn and self.fuse_layer and self.act in (1, 2)
             )
             if rows_path:
-                # 129..256 tokens: QKV rows -> attention core -> (out-proj + FFN) rows per layer.  The batch goes through
-                # the whole layer stack in chunks whose q / k / v / attention scratch (one chunk's worth, shared by all
-                # chunks) stays in the 256 MB memory-side cache instead of streaming through HBM.
+                # 129..256 tokens: (LN1 + QKV + attention) -> (out-proj + FFN) rows per layer.  tf_chunk > 0 sends the batch
+                # through the whole layer stack in chunks that share one chunk's worth of scratch.
                 free = [i for i in range(5) if i != x]
                 src, dst, q, t, h = x, free[0], free[1], free[2], free[3]
                 chunk = self.tf_chunk if 0 < self.tf_chunk < B else B
