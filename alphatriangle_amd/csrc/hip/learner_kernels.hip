@@ -449,6 +449,74 @@ void ln_bwd_launch(const void* x, const void* dy, const float* g, const float* m
 }
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Patch matrix (im2col, stride 1) of a channel-major activation: x [C, B, H, W] bf16 -> cols [C*kh*kw, B*oh*ow],
+// row (c, ky, kx), column (b, oy, ox), zeros where the tap falls off the board.  This is the B operand of the
+// learner's convolution GEMMs (forward: the layer input; data gradient: the output gradient); channel-major
+// activations make the GEMM output [Cout, B*oh*ow] the next layer's input as it stands, so the convolution body of
+// the learner needs no layout copies.  One thread = 8 consecutive columns of all kh*kw rows of one channel (the
+// column decode is shared by the taps; every store is 16 bytes, coalesced along the row).
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void patch_matrix_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ cols,
+                                                          int C, int B, int H, int W, int ph, int pw, int oh, int ow) {
+  const int groups = (B * oh * ow) >> 3;  // 8-column groups per row (host checks divisibility)
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (tid >= (long long)C * groups) return;
+  const int c = (int)(tid / groups), g = (int)(tid - (long long)c * groups);
+  const int n0 = g << 3;
+  const int plane = oh * ow;
+  int b = n0 / plane, rem = n0 - b * plane;
+  int oy = rem / ow, ox = rem - oy * ow;
+  // input offsets (without the tap shift) and coordinates of the 8 columns
+  int iy[8], ix[8], base[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    iy[i] = oy - ph;
+    ix[i] = ox - pw;
+    base[i] = ((c * B + b) * H + iy[i]) * W + ix[i];
+    if (++ox == ow) {
+      ox = 0;
+      if (++oy == oh) {
+        oy = 0;
+        ++b;
+      }
+    }
+  }
+  const size_t row_pitch = (size_t)B * plane;
+  unsigned short* out = cols + (size_t)c * KH * KW * row_pitch + n0;
+#pragma unroll
+  for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {
+      unsigned short v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int yy = iy[i] + ky, xx = ix[i] + kx;
+        const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        v[i] = in ? x[base[i] + ky * W + kx] : (unsigned short)0;
+      }
+      uint4 o;
+      o.x = v[0] | ((unsigned)v[1] << 16);
+      o.y = v[2] | ((unsigned)v[3] << 16);
+      o.z = v[4] | ((unsigned)v[5] << 16);
+      o.w = v[6] | ((unsigned)v[7] << 16);
+      *reinterpret_cast<uint4*>(out + (size_t)(ky * KW + kx) * row_pitch) = o;
+    }
+}
+
+template <int KH, int KW>
+static int launch_patch_matrix(const void* x, void* cols, int C, int B, int H, int W, int ph, int pw, hipStream_t s) {
+  const int oh = H + 2 * ph - KH + 1, ow = W + 2 * pw - KW + 1;
+  if (oh <= 0 || ow <= 0 || ((B * oh * ow) & 7) != 0) return -2;
+  const long long threads = (long long)C * ((B * oh * ow) >> 3);
+  const long long blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffLL || (long long)C * B * H * W > 0x7fffffffLL) return -3;
+  hipLaunchKernelGGL((patch_matrix_kernel<KH, KW>), dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)x,
+                     (unsigned short*)cols, C, B, H, W, ph, pw, oh, ow);
+  return (int)hipGetLastError();
+}
+
 extern "C" {
 
 int atri_az_loss(const float* plog, const float* vlog, const float* ptgt, const float* ret, const float* isw,
@@ -568,6 +636,15 @@ int atri_ln_bwd(const void* x, const void* dy, int is_bf16, const float* g, cons
   hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, partial, dgamma, blocks, 2 * D);
   (void)dbeta;  // dgamma and dbeta are the two halves of one [2 * D] buffer
   return (int)hipGetLastError();
+}
+
+// cols [C*kh*kw, B*oh*ow] = patch matrix of x [C, B, H, W] (bf16, stride 1, zero padding ph / pw); 3x3 and 5x5 kernels.
+int atri_patch_matrix(const void* x, void* cols, int C, int B, int H, int W, int kh, int kw, int ph, int pw, hipStream_t s) {
+  if (C <= 0 || B <= 0) return 0;
+  if (ph < 0 || pw < 0 || ph >= kh || pw >= kw) return -1;
+  if (kh == 3 && kw == 3) return launch_patch_matrix<3, 3>(x, cols, C, B, H, W, ph, pw, s);
+  if (kh == 5 && kw == 5) return launch_patch_matrix<5, 5>(x, cols, C, B, H, W, ph, pw, s);
+  return -1;
 }
 
 // Node census of a captured (not yet instantiated) HIP graph: counts[0] = kernel nodes, counts[1] = memset nodes,

@@ -96,6 +96,57 @@ class _ConvGemm(torch.autograd.Function):
         return d_x, d_w, None, None
 
 
+class _ConvGemmCM(torch.autograd.Function):
+    """:class:`_ConvGemm` on channel-major activations: ``x [Cin, B, H, W]`` -> ``[Cout, B, oh, ow]``.
+
+    With the batch folded into the column dimension the GEMM output ``[Cout, B*oh*ow]`` IS the next layer's input, and
+    the incoming gradient is the GEMM operand as it stands: no NCHW <-> channel-major copies anywhere (the NCHW form
+    spends about ten strided-copy launches per convolution and step on padding, gathering and permuting).  The patch
+    matrices come from one HIP launch each (``ops.hip_learner.patch_matrix_cm``).
+    """
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, ph: int, pw: int) -> torch.Tensor:  # noqa: ANN001
+        from ..ops import hip_learner
+
+        cin, b, h, w = x.shape
+        cout, _, kh, kw = weight.shape
+        if kh == 1 and kw == 1:
+            cols = x.reshape(cin, b * h * w)
+        else:
+            cols = hip_learner.patch_matrix_cm(x, kh, kw, ph, pw)
+        ctx.save_for_backward(cols, weight)
+        ctx.geom = (b, h, w, ph, pw)
+        oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+        return (weight.reshape(cout, -1) @ cols).view(cout, b, oh, ow)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        cols, weight = ctx.saved_tensors
+        b, h, w, ph, pw = ctx.geom
+        cout, cin, kh, kw = weight.shape
+        g = grad_out.contiguous()
+        d_x = d_w = None
+        if ctx.needs_input_grad[1]:
+            k, n = cols.shape
+            g2 = g.view(cout, n)
+            s = _split_count(n)
+            parts = torch.bmm(g2.view(cout, s, n // s).transpose(0, 1), cols.view(k, s, n // s).permute(1, 2, 0))
+            d_w = parts.sum(0, dtype=_grad_dtype(parts)).view(cout, cin, kh, kw)
+        if ctx.needs_input_grad[0]:
+            if kh == 1 and kw == 1:
+                d_x = (weight.reshape(cout, cin).t() @ g.view(cout, -1)).view(cin, b, h, w)
+            else:
+                g_cols = hip_learner.patch_matrix_cm(g, kh, kw, kh - 1 - ph, kw - 1 - pw)  # [Cout*kh*kw, B*H*W]
+                w_t = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * kh * kw)
+                d_x = (w_t @ g_cols).view(cin, b, h, w)
+        return d_x, d_w, None, None
+
+
 class GemmConv2d(nn.Conv2d):
     """``nn.Conv2d`` (same parameters, same ``state_dict`` keys) whose GPU path is im2col + GEMM.
 
@@ -124,6 +175,27 @@ class GemmConv2d(nn.Conv2d):
         out = _ConvGemm.apply(x, self.weight, int(self.padding[0]), int(self.padding[1]))
         if self.bias is not None:
             out = out + self.bias.to(out.dtype).view(1, -1, 1, 1)
+        return out
+
+    def cm_ok(self, batch: int, h: int, w: int) -> bool:
+        """Whether :meth:`cm_forward` handles this layer for ``batch`` boards of ``h x w`` (bf16 autocast on a GPU)."""
+        if self.stride != (1, 1) or self.dilation != (1, 1) or self.groups != 1 or isinstance(self.padding, str):
+            return False
+        kh, kw = self.kernel_size
+        ph, pw = self.padding
+        if self.padding_mode != "zeros" or kh - 1 < ph or kw - 1 < pw:
+            return False
+        if (kh, kw) == (1, 1):
+            return (ph, pw) == (0, 0)
+        oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+        # forward gathers the input, the data gradient gathers the output gradient: both column counts in eights
+        return (kh, kw) in ((3, 3), (5, 5)) and oh > 0 and ow > 0 and (batch * oh * ow) % 8 == 0 and (batch * h * w) % 8 == 0
+
+    def cm_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Channel-major form: ``[Cin, B, H, W]`` -> ``[Cout, B, oh, ow]`` (see :class:`_ConvGemmCM`)."""
+        out = _ConvGemmCM.apply(x, self.weight, int(self.padding[0]), int(self.padding[1]))
+        if self.bias is not None:
+            out = out + self.bias.to(out.dtype).view(-1, 1, 1, 1)
         return out
 
 
@@ -420,8 +492,55 @@ class AlphaTriangleNet(nn.Module):
         val.append(nn.Linear(vw, mc.NUM_VALUE_ATOMS))
         self.value_head = nn.Sequential(*val)
 
+    channel_major = True  # learner fast path: convolution body on [C, B, H, W] activations (tests flip this)
+
+    def _cm_plan_ok(self, grid_state: torch.Tensor) -> bool:
+        """The channel-major convolution body needs a GPU, bf16 autocast, the patch-matrix kernel and eligible layers."""
+        if not (self.channel_major and grid_state.is_cuda and grid_state.dim() == 4):
+            return False
+        if not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            return False
+        from ..ops import hip_learner
+
+        if not hip_learner.available():
+            return False
+        b, _, h, w = grid_state.shape
+        for m in list(self.conv_body.modules()) + list(self.res_body.modules()) + [self.input_proj]:
+            if isinstance(m, nn.Conv2d):
+                if not isinstance(m, GemmConv2d) or not m.cm_ok(b, h, w):
+                    return False
+                h = h + 2 * m.padding[0] - m.kernel_size[0] + 1
+                w = w + 2 * m.padding[1] - m.kernel_size[1] + 1
+        return True
+
+    def _cm_apply(self, mod: nn.Module, x: torch.Tensor) -> torch.Tensor:
+        """``mod`` on a channel-major activation ``[C, B, H, W]`` (same parameters, buffers and statistics)."""
+        if isinstance(mod, nn.Sequential):
+            for m in mod:
+                x = self._cm_apply(m, x)
+            return x
+        if isinstance(mod, GemmConv2d):
+            return mod.cm_forward(x)
+        if isinstance(mod, nn.BatchNorm2d):
+            # per-channel statistics over (B, H, W): the channel-major buffer viewed as ONE image of B*H rows
+            c, b, h, w = x.shape
+            return mod(x.reshape(1, c, b * h, w)).view(c, b, h, w)
+        if isinstance(mod, ResidualBlock):
+            y = self._cm_apply(mod.bn2, self._cm_apply(mod.conv2, self._cm_apply(mod.conv1, x)))
+            return mod.activation(y + x)
+        return mod(x)  # activations and Identity are layout-agnostic
+
     def body(self, grid_state: torch.Tensor) -> torch.Tensor:
         """Feature extractor up to (and excluding) the shared FC: returns ``[B, feat]``."""
+        if self._cm_plan_ok(grid_state):
+            x = grid_state.permute(1, 0, 2, 3)  # [C, B, H, W]: a view for the usual single input channel
+            x = self._cm_apply(self.res_body, self._cm_apply(self.conv_body, x))
+            if self.uses_transformer and self.transformer_body is not None and self.pos_encoder is not None:
+                x = self._cm_apply(self.input_proj, x)
+                tokens = x.flatten(2).permute(2, 1, 0).contiguous()  # [H*W, B, D]
+                tokens = self.transformer_body(self.pos_encoder(tokens))
+                return tokens.permute(1, 0, 2).flatten(1)
+            return x.permute(1, 0, 2, 3).reshape(x.size(1), -1)
         x = self.res_body(self.conv_body(grid_state))
         if self.uses_transformer and self.transformer_body is not None and self.pos_encoder is not None:
             x = self.input_proj(x)

@@ -149,3 +149,31 @@ def per_sample(tree: torch.Tensor, P: int, size: int, batch: int, rnd: torch.Ten
 
 def per_priorities(tree: torch.Tensor, P: int, idx: torch.Tensor, err: torch.Tensor, alpha: float, eps: float, max_prio: torch.Tensor) -> None:
     hb.call("atri_per_priorities", hb.ptr(tree), hb.i64(P), hb.ptr(idx), hb.ptr(err), hb.i32(idx.numel()), hb.f32(alpha), hb.f32(eps), hb.ptr(max_prio))
+
+
+def patch_matrix_supported(x: torch.Tensor, kh: int, kw: int, ph: int, pw: int) -> bool:
+    """True when :func:`patch_matrix_cm` can build the patch matrix of ``x`` ``[C, B, H, W]``."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and available()):
+        return False
+    if (kh, kw) not in ((3, 3), (5, 5)) or not (0 <= ph < kh and 0 <= pw < kw):
+        return False
+    c, b, h, w = x.shape
+    oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+    return oh > 0 and ow > 0 and (b * oh * ow) % 8 == 0 and c * kh * kw * b * oh * ow < 2**40 and c * b * h * w < 2**31
+
+
+def patch_matrix_cm(x: torch.Tensor, kh: int, kw: int, ph: int, pw: int) -> torch.Tensor:
+    """Stride-1 im2col of a channel-major activation ``[C, B, H, W]`` (bf16) -> ``[C*kh*kw, B*oh*ow]`` in one launch.
+
+    Row order ``(c, ky, kx)``, column order ``(b, oy, ox)``: the B operand of the learner's convolution GEMMs
+    (``patch_matrix_kernel`` in csrc/hip/learner_kernels.hip).
+    """
+    if not patch_matrix_supported(x, kh, kw, ph, pw):
+        raise ValueError("patch_matrix_cm: unsupported input (needs a CUDA bf16 [C, B, H, W] tensor, 3x3 or 5x5 taps)")
+    x = x.contiguous()
+    c, b, h, w = x.shape
+    oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+    cols = torch.empty(c * kh * kw, b * oh * ow, dtype=torch.bfloat16, device=x.device)
+    hb.call("atri_patch_matrix", hb.ptr(x), hb.ptr(cols), hb.i32(c), hb.i32(b), hb.i32(h), hb.i32(w), hb.i32(kh), hb.i32(kw),
+            hb.i32(ph), hb.i32(pw))
+    return cols

@@ -244,3 +244,69 @@ def test_layer_norm_kernels_match_torch(rows, d, dtype):
     assert (gx.float() - gxr).abs().max().item() < tol * max(1.0, gxr.abs().max().item())
     assert torch.allclose(gw.float(), gwr, rtol=1e-3, atol=1e-3 * rows ** 0.5)
     assert torch.allclose(gb.float(), gbr, rtol=1e-3, atol=1e-3 * rows ** 0.5)
+
+
+@pytest.mark.parametrize("c,b,h,w,k,p", [(128, 256, 8, 15, 3, 1), (1, 256, 8, 15, 3, 1), (32, 64, 8, 15, 3, 0), (16, 8, 12, 21, 5, 2),
+                                         (64, 32, 5, 9, 3, 2)])
+def test_patch_matrix_kernel_matches_torch_gather(c, b, h, w, k, p):
+    """patch_matrix_kernel (channel-major im2col, one launch) against strided-view gathering in PyTorch: exact copies."""
+    from alphatriangle_amd.models.model import _patch_matrix
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(c + b)
+    dev = torch.device("cuda")
+    x = torch.randn(c, b, h, w, device=dev).to(torch.bfloat16)
+    assert hip_learner.patch_matrix_supported(x, k, k, p, p)
+    cols = hip_learner.patch_matrix_cm(x, k, k, p, p)
+    ref = _patch_matrix(x.permute(1, 0, 2, 3).contiguous(), k, k, p, p)
+    torch.cuda.synchronize()
+    assert cols.shape == ref.shape
+    assert torch.equal(cols, ref)
+
+
+@pytest.mark.parametrize("preset", ["default", "cnn"])
+def test_channel_major_conv_body_matches_nchw_path(preset):
+    """The learner's channel-major convolution body (patch-matrix kernel, no layout copies) against the NCHW form of the
+    same module: same outputs, same gradients (bf16 autocast), same BatchNorm running statistics."""
+    import copy
+
+    from alphatriangle_amd.models.model import AlphaTriangleNet
+
+    torch.manual_seed(21)
+    dev = torch.device("cuda")
+    env = EnvConfig()
+    mc = ModelConfig() if preset == "default" else ModelConfig.cnn_only()
+    net_a = AlphaTriangleNet(mc, env).to(dev).train()
+    net_b = copy.deepcopy(net_a)
+    net_b.channel_major = False
+    for m in list(net_a.modules()) + list(net_b.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    B = 256
+    grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    net_r = copy.deepcopy(net_a)  # fp32 reference, no autocast
+    net_r.channel_major = False
+    outs, grads = [], []
+    for net in (net_a, net_b, net_r):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=net is not net_r):
+            assert net._cm_plan_ok(grid) == (net is net_a)
+            pl, vl = net(grid, other)
+            loss = pl.float().square().mean() + vl.float().square().mean()
+        loss.backward()
+        outs.append((pl.float().detach(), vl.float().detach()))
+        grads.append({n: p.grad.float() for n, p in net.named_parameters()})
+    torch.cuda.synchronize()
+    # both bf16 paths are compared with the fp32 run: the channel-major path may not be further from it than the NCHW path
+    for i in (0, 1):
+        err_cm = (outs[0][i] - outs[2][i]).abs().max().item()
+        err_nchw = (outs[1][i] - outs[2][i]).abs().max().item()
+        assert err_cm < 1.5 * err_nchw + 0.02, (i, err_cm, err_nchw)
+    for name, gr in grads[2].items():
+        scale = gr.abs().max().item() + 1e-6
+        err_cm = (grads[0][name] - gr).abs().max().item() / scale
+        err_nchw = (grads[1][name] - gr).abs().max().item() / scale
+        assert err_cm < 1.5 * err_nchw + 0.03, (name, err_cm, err_nchw)
+    for (name, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        if "running" in name:
+            assert torch.allclose(ba.float(), bb.float(), rtol=2e-2, atol=2e-3), name
