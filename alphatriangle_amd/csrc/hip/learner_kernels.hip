@@ -455,26 +455,43 @@ void ln_bwd_launch(const void* x, const void* dy, const float* g, const float* m
 // row (c, ky, kx), column (b, oy, ox), zeros where the tap falls off the board.  This is the B operand of the
 // learner's convolution GEMMs (forward: the layer input; data gradient: the output gradient); channel-major
 // activations make the GEMM output [Cout, B*oh*ow] the next layer's input as it stands, so the convolution body of
-// the learner needs no layout copies.  One thread = 8 consecutive columns of all kh*kw rows of one channel (the
-// column decode is shared by the taps; every store is 16 bytes, coalesced along the row).
+// the learner needs no layout copies.
+// One workgroup = 2048 consecutive columns of all kh*kw rows of one channel.  The columns' source pixels are one
+// contiguous run of whole boards of that channel: they are staged in LDS with coalesced loads, and the scattered
+// 2-byte tap reads then hit LDS instead of global memory; one thread = 8 consecutive columns (the column decode is
+// shared by the taps; every store is 16 bytes, coalesced along the row).
+constexpr int kPatchCols = 2048;
+
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void patch_matrix_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ cols,
-                                                          int C, int B, int H, int W, int ph, int pw, int oh, int ow) {
-  const int groups = (B * oh * ow) >> 3;  // 8-column groups per row (host checks divisibility)
-  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (tid >= (long long)C * groups) return;
-  const int c = (int)(tid / groups), g = (int)(tid - (long long)c * groups);
-  const int n0 = g << 3;
-  const int plane = oh * ow;
+                                                          int B, int H, int W, int ph, int pw, int oh, int ow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short tile[];
+  const int c = blockIdx.y, tid = threadIdx.x;
+  const int plane = oh * ow, n_total = B * plane;
+  const int n_begin = blockIdx.x * kPatchCols, n_end = min(n_total, n_begin + kPatchCols);
+  const int b_lo = n_begin / plane, b_hi = (n_end - 1) / plane;
+  const int board = H * W, count = (b_hi - b_lo + 1) * board;
+  const unsigned short* src = x + ((size_t)c * B + b_lo) * board;
+  if (((((size_t)c * B + b_lo) * board) & 1) == 0) {  // run starts on a 4-byte boundary: dword loads
+    const unsigned* src2 = reinterpret_cast<const unsigned*>(src);
+    unsigned* tile2 = reinterpret_cast<unsigned*>(tile);
+    for (int i = tid; i < (count >> 1); i += 256) tile2[i] = src2[i];
+    if ((count & 1) && tid == 0) tile[count - 1] = src[count - 1];
+  } else {
+    for (int i = tid; i < count; i += 256) tile[i] = src[i];
+  }
+  __syncthreads();
+  const int n0 = n_begin + (tid << 3);
+  if (n0 >= n_end) return;  // after the only barrier
   int b = n0 / plane, rem = n0 - b * plane;
   int oy = rem / ow, ox = rem - oy * ow;
-  // input offsets (without the tap shift) and coordinates of the 8 columns
+  b -= b_lo;
   int iy[8], ix[8], base[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     iy[i] = oy - ph;
     ix[i] = ox - pw;
-    base[i] = ((c * B + b) * H + iy[i]) * W + ix[i];
+    base[i] = (b * H + iy[i]) * W + ix[i];
     if (++ox == ow) {
       ox = 0;
       if (++oy == oh) {
@@ -483,7 +500,7 @@ __global__ __launch_bounds__(256) void patch_matrix_kernel(const unsigned short*
       }
     }
   }
-  const size_t row_pitch = (size_t)B * plane;
+  const size_t row_pitch = (size_t)n_total;
   unsigned short* out = cols + (size_t)c * KH * KW * row_pitch + n0;
 #pragma unroll
   for (int ky = 0; ky < KH; ++ky)
@@ -494,7 +511,7 @@ __global__ __launch_bounds__(256) void patch_matrix_kernel(const unsigned short*
       for (int i = 0; i < 8; ++i) {
         const int yy = iy[i] + ky, xx = ix[i] + kx;
         const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        v[i] = in ? x[base[i] + ky * W + kx] : (unsigned short)0;
+        v[i] = in ? tile[base[i] + ky * W + kx] : (unsigned short)0;
       }
       uint4 o;
       o.x = v[0] | ((unsigned)v[1] << 16);
@@ -508,12 +525,14 @@ __global__ __launch_bounds__(256) void patch_matrix_kernel(const unsigned short*
 template <int KH, int KW>
 static int launch_patch_matrix(const void* x, void* cols, int C, int B, int H, int W, int ph, int pw, hipStream_t s) {
   const int oh = H + 2 * ph - KH + 1, ow = W + 2 * pw - KW + 1;
-  if (oh <= 0 || ow <= 0 || ((B * oh * ow) & 7) != 0) return -2;
-  const long long threads = (long long)C * ((B * oh * ow) >> 3);
-  const long long blocks = (threads + 255) / 256;
-  if (blocks > 0x7fffffffLL || (long long)C * B * H * W > 0x7fffffffLL) return -3;
-  hipLaunchKernelGGL((patch_matrix_kernel<KH, KW>), dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)x,
-                     (unsigned short*)cols, C, B, H, W, ph, pw, oh, ow);
+  if (oh <= 0 || ow <= 0 || (((long long)B * oh * ow) & 7) != 0) return -2;
+  if ((long long)C * B * H * W > 0x7fffffffLL || (long long)B * oh * ow > 0x7fffffffLL || C > 65535) return -3;
+  const int n_total = B * oh * ow;
+  const int boards = kPatchCols / (oh * ow) + 2;  // most boards one workgroup's columns can touch
+  const size_t lds = ((size_t)boards * H * W * 2 + 15) & ~(size_t)15;
+  if (lds > 64 * 1024) return -4;
+  hipLaunchKernelGGL((patch_matrix_kernel<KH, KW>), dim3((n_total + kPatchCols - 1) / kPatchCols, C), dim3(256), lds, s,
+                     (const unsigned short*)x, (unsigned short*)cols, B, H, W, ph, pw, oh, ow);
   return (int)hipGetLastError();
 }
 

@@ -159,7 +159,9 @@ def patch_matrix_supported(x: torch.Tensor, kh: int, kw: int, ph: int, pw: int) 
         return False
     c, b, h, w = x.shape
     oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-    return oh > 0 and ow > 0 and (b * oh * ow) % 8 == 0 and c * kh * kw * b * oh * ow < 2**40 and c * b * h * w < 2**31
+    if oh <= 0 or ow <= 0 or (b * oh * ow) % 8 != 0 or c > 65535 or c * b * h * w >= 2**31 or b * oh * ow >= 2**31:
+        return False
+    return (2048 // (oh * ow) + 2) * h * w * 2 <= 64 * 1024  # boards one workgroup stages in LDS
 
 
 def patch_matrix_cm(x: torch.Tensor, kh: int, kw: int, ph: int, pw: int) -> torch.Tensor:
