@@ -12,7 +12,6 @@ import logging
 import shutil
 import subprocess
 import sys
-from pathlib import Path
 from typing import Annotated
 
 import typer
@@ -20,7 +19,7 @@ from rich.console import Console
 from rich.panel import Panel
 from rich.text import Text
 
-from .config import APP_NAME, AlphaTriangleMCTSConfig, EnvConfig, ModelConfig, SystemConfig, TrainConfig
+from .config import APP_NAME, TrainConfig
 from .logging_config import setup_logging
 from .stats import PersistenceConfig, TrieyeConfig
 

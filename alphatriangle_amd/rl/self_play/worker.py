@@ -19,7 +19,6 @@ from pathlib import Path
 from typing import Any
 
 import numpy as np
-import torch
 
 from ...config.env_config import EnvConfig
 from ...config.mcts_config import AlphaTriangleMCTSConfig
@@ -30,7 +29,7 @@ from ...features.extractor import extract_state_features
 from ...mcts.host_search import run_mcts
 from ...models.network import NeuralNetwork
 from ...stats.events import RawMetricEvent
-from ...utils.helpers import get_device, set_random_seeds
+from ...utils.helpers import get_device
 from ...utils.types import Experience
 from ..types import SelfPlayResult
 from .mcts_helpers import PolicyGenerationError, get_policy_target_from_visits, select_action_from_visits

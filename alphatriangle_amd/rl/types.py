@@ -8,8 +8,6 @@ from typing import Any
 import numpy as np
 from pydantic import BaseModel, ConfigDict, Field, model_validator
 
-from ..utils.types import Experience
-
 logger = logging.getLogger(__name__)
 
 

@@ -15,9 +15,6 @@ import threading
 import time
 from typing import Any
 
-import numpy as np
-import torch
-
 from ..rl.core.trainer import TensorBatch
 from ..rl.types import SelfPlayResult
 from ..stats.events import RawMetricEvent

@@ -14,7 +14,6 @@ from typing import Any
 import torch
 
 from ..config import (
-    APP_NAME,
     AlphaTriangleMCTSConfig,
     EnvConfig,
     ModelConfig,

@@ -13,7 +13,6 @@ from __future__ import annotations
 import concurrent.futures as cf
 import logging
 import threading
-from typing import Any
 
 from ..rl.self_play.worker import SelfPlayWorker
 from ..rl.types import SelfPlayResult
