@@ -858,13 +858,15 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnCoreArgs a) {
   }
 }
 
-// LayerNorm1 + QKV projection + attention core of one (sample, head pair) per workgroup, for 129..256 tokens:
-// Q, K and V never go to memory.  Eight waves: wave (hh, quarter) owns head 2*pair + hh and the 64 tokens of its
-// quarter.  It loads those rows straight into MFMA operand registers (no LDS tile), normalises them in registers
-// (LayerNorm's affine part is folded into the weights by the host), and produces Q (kept), K and V^T of its tokens.
-// The K / V^T operand images go through LDS lane-linearly - producer and consumer lanes hold identical fragments,
-// so the exchange is a conflict-free register dump of 64 KB - and after one barrier every wave holds the K and
-// V^T fragments of all 256 key slots of its head and runs its four query tiles exactly like attn_core_kernel.
+// LayerNorm1 + QKV projection + attention core of one sample per workgroup, for 129..256 tokens: Q, K and V never go to
+// memory.  Sixteen waves: wave (pair, octant) owns heads 2*pair and 2*pair + 1 for the 32 tokens of its octant.  It
+// loads those rows straight into MFMA operand registers (no LDS tile), normalises them in registers once for both
+// heads (LayerNorm's affine part is folded into the weights by the host) and produces Q (kept), K and V^T of its
+// tokens.  The K / V^T operand images go through LDS lane-linearly - producer and consumer lanes hold identical
+// fragments, so the exchange is a conflict-free register dump of 128 KB - and after one barrier every wave runs its
+// four (head, query tile) pairs like attn_core_kernel, reading the K / V^T fragments of all 256 key slots from LDS at
+// every use: 128 VGPRs, so the sixteen waves share the CU four to a SIMD and fill each other's
+// MFMA -> softmax -> MFMA dependency stalls.
 struct QkvAttnArgs {
   const unsigned short* x;     // [B, HW, 128]
   const unsigned short* wqkv;  // packed, LayerNorm affine folded in, Q pre-scaled by log2(e)/sqrt(32)
@@ -873,7 +875,7 @@ struct QkvAttnArgs {
   int B, HW;
   float ln_eps;
 };
-constexpr int kQkvAttnLds = 2 * (16 + 16) * 1024;
+constexpr int kQkvAttnLds = 4 * (16 + 16) * 1024;
 
 template <bool SWAP, int MT>
 __device__ __forceinline__ void gemm_regs(float4v (&acc)[MT][2], const WFrags& w, const short8 (&xf)[MT][4]) {
@@ -891,65 +893,59 @@ __device__ __forceinline__ void gemm_regs(float4v (&acc)[MT][2], const WFrags& w
     }
 }
 
-// KTF as in attn_core_kernel: index of the first key tile that holds padding when known at compile time, else -1.
-// The wave's 64 tokens go through the projections in two passes of 32 (the weight fragments are re-read from L1 / L2),
-// and the attention loop reads its K / V^T fragments from LDS at every use: under 128 VGPRs, so two workgroups
-// (16 waves) share a CU and fill each other's MFMA -> softmax -> MFMA dependency stalls.
+// KTF >= 0: index of the first key tile that holds padding, known at compile time (token count in (16 KTF, 16 KTF + 16]);
+// KTF < 0 derives it from the token count.
 template <int KTF>
-__global__ __launch_bounds__(512, 4) void qkv_attn_kernel(QkvAttnArgs a) {
+__global__ __launch_bounds__(1024, 4) void qkv_attn_kernel(QkvAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hh = wave >> 2, quarter = wave & 3;
+  const int pair = wave >> 3, oct = wave & 7;
   const int q4 = lane >> 4, l15 = lane & 15;
-  // workgroups blk and blk + 8 land on the same XCD (hence the same L2) and share a sample
-  const int blk = blockIdx.x;
-  const int pair = (blk >> 3) & 1;
-  const int b = (blk >> 4) * 8 + (blk & 7);
-  if (b >= a.B) return;  // uniform over the workgroup, ahead of the barrier
-  const int head = pair * 2 + hh;
+  const int b = blockIdx.x;
   const int HW = a.HW;
   const unsigned short* xg = a.x + (size_t)b * HW * kD;
-  const short8* wq = reinterpret_cast<const short8*>(a.wqkv) + (size_t)head * 128 + lane;
-  short8* kimg = reinterpret_cast<short8*>(smem) + (size_t)hh * 16 * 64 + lane;               // [2][16 kt][64]
-  short8* vimg = reinterpret_cast<short8*>(smem + 32 * 1024) + (size_t)hh * 16 * 64 + lane;  // [2][8 kb][2 n][64]
+  short8* kimg = reinterpret_cast<short8*>(smem) + lane;              // [4 heads][16 kt][64]
+  short8* vimg = reinterpret_cast<short8*>(smem + 64 * 1024) + lane;  // [4 heads][8 kb][2 n][64]
 
-  short8 Qf[4];
+  short8 xf[2][4];
 #pragma unroll
-  for (int tp = 0; tp < 2; ++tp) {
+  for (int t = 0; t < 2; ++t) {
+    const int tok = min(oct * 32 + t * 16 + l15, HW - 1);  // padding rows repeat the last token (finite, masked as keys)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) xf[t][kc] = *reinterpret_cast<const short8*>(xg + (size_t)tok * kD + kc * 32 + q4 * 8);
+  }
+  // LayerNorm in registers: a token's 128 channels sit in the four lanes that share l15, 32 values each
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = bf16_to_float((unsigned short)xf[t][kc][j]);
+        s += v;
+        ss += v * v;
+      }
+    s = quad_row_sum(s);
+    ss = quad_row_sum(ss);
+    const float mean = s * (1.0f / kD);
+    const float rstd = rsqrtf(fmaxf(ss * (1.0f / kD) - mean * mean, 0.f) + a.ln_eps);
+    const float shift = -mean * rstd;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = bf16_to_float((unsigned short)xf[t][kc][j]) * rstd + shift;
+      xf[t][kc] = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+    }
+  }
+  short8 Qf[2][2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int head = pair * 2 + hh;
+    const short8* wq = reinterpret_cast<const short8*>(a.wqkv) + (size_t)head * 128 + lane;
     WFrags w;
     load_wfrags(w, wq + (size_t)4 * 512);  // K weights
-    short8 xf[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int tok = min(quarter * 64 + (tp * 2 + t) * 16 + l15, HW - 1);  // padding rows repeat the last token (finite, masked as keys)
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) xf[t][kc] = *reinterpret_cast<const short8*>(xg + (size_t)tok * kD + kc * 32 + q4 * 8);
-    }
-    // LayerNorm in registers: a token's 128 channels sit in the four lanes that share l15, 32 values each
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float s = 0.f, ss = 0.f;
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v = bf16_to_float((unsigned short)xf[t][kc][j]);
-          s += v;
-          ss += v * v;
-        }
-      s = quad_row_sum(s);
-      ss = quad_row_sum(ss);
-      const float mean = s * (1.0f / kD);
-      const float rstd = rsqrtf(fmaxf(ss * (1.0f / kD) - mean * mean, 0.f) + a.ln_eps);
-      const float shift = -mean * rstd;
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) {
-        float o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = bf16_to_float((unsigned short)xf[t][kc][j]) * rstd + shift;
-        xf[t][kc] = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
-      }
-    }
     {  // ---- K of these 32 tokens -> LDS image
       float bias[8];
 #pragma unroll
@@ -962,7 +958,7 @@ __global__ __launch_bounds__(512, 4) void qkv_attn_kernel(QkvAttnArgs a) {
       }
       gemm_regs<false, 2>(acc, w, xf);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) kimg[(quarter * 4 + tp * 2 + t) * 64] = pack8(acc[t][0], acc[t][1]);
+      for (int t = 0; t < 2; ++t) kimg[(head * 16 + oct * 2 + t) * 64] = pack8(acc[t][0], acc[t][1]);
     }
     load_wfrags(w, wq + (size_t)8 * 512);  // V weights
     {  // ---- V with swapped operands: acc[t][n][j] = V[token t*16 + 4 q4 + j][dim perm(l15, n)] -> V^T operand images
@@ -976,7 +972,7 @@ __global__ __launch_bounds__(512, 4) void qkv_attn_kernel(QkvAttnArgs a) {
       }
       gemm_regs<true, 2>(acc, w, xf);
 #pragma unroll
-      for (int n = 0; n < 2; ++n) vimg[((quarter * 2 + tp) * 2 + n) * 64] = pack8(acc[0][n], acc[1][n]);
+      for (int n = 0; n < 2; ++n) vimg[((head * 8 + oct) * 2 + n) * 64] = pack8(acc[0][n], acc[1][n]);
     }
     load_wfrags(w, wq);  // Q weights
     {  // ---- Q of these 32 tokens stays in registers
@@ -991,54 +987,60 @@ __global__ __launch_bounds__(512, 4) void qkv_attn_kernel(QkvAttnArgs a) {
       }
       gemm_regs<false, 2>(acc, w, xf);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) Qf[tp * 2 + t] = pack8(acc[t][0], acc[t][1]);
+      for (int t = 0; t < 2; ++t) Qf[hh][t] = pack8(acc[t][0], acc[t][1]);
     }
   }
   __syncthreads();
 
   const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
   const int kt_full = KTF >= 0 ? KTF : HW >> 4;  // key tiles below this index hold no padding
-  unsigned short* og = a.att + (size_t)b * HW * kD + head * 32 + q4 * 8;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int q0 = quarter * 64 + t * 16;
-    if (q0 >= HW) break;  // wave-uniform
-    __builtin_amdgcn_sched_barrier(0);  // keep query tiles from interleaving: each holds 64 score registers
-    float4v st[16];
-    float m = -1e30f;
+  for (int hh = 0; hh < 2; ++hh) {
+    const int head = pair * 2 + hh;
+    const short8* kh = kimg + head * 16 * 64;
+    const short8* vh = vimg + head * 16 * 64;
+    unsigned short* og = a.att + (size_t)b * HW * kD + head * 32 + q4 * 8;
 #pragma unroll
-    for (int kt = 0; kt < 16; ++kt) {
-      st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg[kt * 64], Qf[t], (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      if (kt >= kt_full) {
+    for (int t = 0; t < 2; ++t) {
+      const int q0 = oct * 32 + t * 16;
+      if (q0 >= HW) break;  // wave-uniform
+      __builtin_amdgcn_sched_barrier(0);  // keep query tiles from interleaving: each holds 64 score registers
+      float4v st[16];
+      float m = -1e30f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
+      for (int kt = 0; kt < 16; ++kt) {
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kt * 64], Qf[hh][t], (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (kt >= kt_full) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
       }
+      m = quad_row_max(m);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
+      for (int kt = 0; kt < 16; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st[kt][j] = __builtin_amdgcn_exp2f(st[kt][j] - m);  // scores arrive in log2 units
+      // O^T = V^T P^T; a ones fragment as a third "V^T" tile yields the softmax denominators from the same MFMA pass
+      float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f}, os = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        const short8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[(kb * 2 + 0) * 64], pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[(kb * 2 + 1) * 64], pf, o1, 0, 0, 0);
+        os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
+      }
+      const float inv = __builtin_amdgcn_rcpf(os[0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o0[j] *= inv;
+        o1[j] *= inv;
+      }
+      // lane holds channels head*32 + q4*8 .. +7 of query q0 + l15
+      if (q0 + l15 < HW) *reinterpret_cast<short8*>(og + (size_t)(q0 + l15) * kD) = pack8(o0, o1);
     }
-    m = quad_row_max(m);
-#pragma unroll
-    for (int kt = 0; kt < 16; ++kt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) st[kt][j] = __builtin_amdgcn_exp2f(st[kt][j] - m);  // scores arrive in log2 units
-    // O^T = V^T P^T; a ones fragment as a third "V^T" tile yields the softmax denominators from the same MFMA pass
-    float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f}, os = (float4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-      const short8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
-      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vimg[(kb * 2 + 0) * 64], pf, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vimg[(kb * 2 + 1) * 64], pf, o1, 0, 0, 0);
-      os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
-    }
-    const float inv = __builtin_amdgcn_rcpf(os[0]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      o0[j] *= inv;
-      o1[j] *= inv;
-    }
-    // lane holds channels head*32 + q4*8 .. +7 of query q0 + l15
-    if (q0 + l15 < HW) *reinterpret_cast<short8*>(og + (size_t)(q0 + l15) * kD) = pack8(o0, o1);
   }
 }
 
@@ -1318,9 +1320,8 @@ static int layer_rows_impl(const void* x, void* out, const void* wqkv, const flo
       attr2 = true;
     }
     QkvAttnArgs fa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, (unsigned short*)att, B, HW, ln1_eps};
-    const int wgs = ((B + 7) / 8) * 16;
-    if (HW > 240) hipLaunchKernelGGL(qkv_attn_kernel<15>, dim3(wgs), dim3(512), kQkvAttnLds, stream, fa);
-    else hipLaunchKernelGGL(qkv_attn_kernel<-1>, dim3(wgs), dim3(512), kQkvAttnLds, stream, fa);
+    if (HW > 240) hipLaunchKernelGGL(qkv_attn_kernel<15>, dim3(B), dim3(1024), kQkvAttnLds, stream, fa);
+    else hipLaunchKernelGGL(qkv_attn_kernel<-1>, dim3(B), dim3(1024), kQkvAttnLds, stream, fa);
   } else {
     QkvRowsArgs qa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, ln1_g, ln1_b, (unsigned short*)q,
                    (unsigned short*)k, (unsigned short*)vt, rows, HW, ln1_eps};
