@@ -893,8 +893,71 @@ __device__ __forceinline__ void gemm_regs(float4v (&acc)[MT][2], const WFrags& w
     }
 }
 
+// The four (head, query tile) pairs of one wave of qkv_attn_kernel.  SAFE subtracts the row maxima before exp2; the
+// other form relies on the caller's range check of the denominators (returned: true when a lane saw one out of range).
 // KTF >= 0: index of the first key tile that holds padding, known at compile time (token count in (16 KTF, 16 KTF + 16]);
 // KTF < 0 derives it from the token count.
+template <int KTF, bool SAFE>
+__device__ __forceinline__ bool qkv_attn_tiles(const QkvAttnArgs& a, const short8* kimg, const short8* vimg,
+                                               const short8 (&Qf)[2][2], int b, int pair, int oct, int q4, int l15) {
+  const int HW = a.HW;
+  const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
+  const int kt_full = KTF >= 0 ? KTF : HW >> 4;  // key tiles below this index hold no padding
+  bool suspect = false;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int head = pair * 2 + hh;
+    const short8* kh = kimg + head * 16 * 64;
+    const short8* vh = vimg + head * 16 * 64;
+    unsigned short* og = a.att + (size_t)b * HW * kD + head * 32 + q4 * 8;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int q0 = oct * 32 + t * 16;
+      if (q0 >= HW) break;  // wave-uniform
+      __builtin_amdgcn_sched_barrier(0);  // keep query tiles from interleaving: each holds 64 score registers
+      float4v st[16];
+      float m = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) {
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kt * 64], Qf[hh][t], (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (kt >= kt_full) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
+        }
+        if (SAFE) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
+        }
+      }
+      if (SAFE) m = quad_row_max(m);
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st[kt][j] = __builtin_amdgcn_exp2f(SAFE ? st[kt][j] - m : st[kt][j]);  // log2 units
+      // O^T = V^T P^T; a ones fragment as a third "V^T" tile yields the softmax denominators from the same MFMA pass
+      float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f}, os = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        const short8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[(kb * 2 + 0) * 64], pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[(kb * 2 + 1) * 64], pf, o1, 0, 0, 0);
+        os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
+      }
+      if (!SAFE) suspect |= !(os[0] > 0x1p-100f && os[0] < 0x1p100f);
+      const float inv = __builtin_amdgcn_rcpf(os[0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o0[j] *= inv;
+        o1[j] *= inv;
+      }
+      // lane holds channels head*32 + q4*8 .. +7 of query q0 + l15
+      if (q0 + l15 < HW) *reinterpret_cast<short8*>(og + (size_t)(q0 + l15) * kD) = pack8(o0, o1);
+    }
+  }
+  return suspect;
+}
+
 template <int KTF>
 __global__ __launch_bounds__(1024, 4) void qkv_attn_kernel(QkvAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -992,56 +1055,12 @@ __global__ __launch_bounds__(1024, 4) void qkv_attn_kernel(QkvAttnArgs a) {
   }
   __syncthreads();
 
-  const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
-  const int kt_full = KTF >= 0 ? KTF : HW >> 4;  // key tiles below this index hold no padding
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    const int head = pair * 2 + hh;
-    const short8* kh = kimg + head * 16 * 64;
-    const short8* vh = vimg + head * 16 * 64;
-    unsigned short* og = a.att + (size_t)b * HW * kD + head * 32 + q4 * 8;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int q0 = oct * 32 + t * 16;
-      if (q0 >= HW) break;  // wave-uniform
-      __builtin_amdgcn_sched_barrier(0);  // keep query tiles from interleaving: each holds 64 score registers
-      float4v st[16];
-      float m = -1e30f;
-#pragma unroll
-      for (int kt = 0; kt < 16; ++kt) {
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kt * 64], Qf[hh][t], (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        if (kt >= kt_full) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
-      }
-      m = quad_row_max(m);
-#pragma unroll
-      for (int kt = 0; kt < 16; ++kt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) st[kt][j] = __builtin_amdgcn_exp2f(st[kt][j] - m);  // scores arrive in log2 units
-      // O^T = V^T P^T; a ones fragment as a third "V^T" tile yields the softmax denominators from the same MFMA pass
-      float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f}, os = (float4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < 8; ++kb) {
-        const short8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
-        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[(kb * 2 + 0) * 64], pf, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[(kb * 2 + 1) * 64], pf, o1, 0, 0, 0);
-        os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
-      }
-      const float inv = __builtin_amdgcn_rcpf(os[0]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o0[j] *= inv;
-        o1[j] *= inv;
-      }
-      // lane holds channels head*32 + q4*8 .. +7 of query q0 + l15
-      if (q0 + l15 < HW) *reinterpret_cast<short8*>(og + (size_t)(q0 + l15) * kD) = pack8(o0, o1);
-    }
-  }
+  // Softmax is shift invariant and bf16 has fp32's exponent range, so the fast pass skips the row maximum altogether
+  // (no max, no subtraction: a quarter of the loop's VALU work) and checks the denominators instead: any query whose
+  // sum left [2^-100, 2^100] (overflow, total underflow, NaN) sends the wave through the max-subtracting pass, which
+  // rewrites its outputs.
+  const bool suspect = qkv_attn_tiles<KTF, false>(a, kimg, vimg, Qf, b, pair, oct, q4, l15);
+  if (__builtin_amdgcn_ballot_w64(suspect) != 0) (void)qkv_attn_tiles<KTF, true>(a, kimg, vimg, Qf, b, pair, oct, q4, l15);
 }
 
 struct ProjRowsArgs {

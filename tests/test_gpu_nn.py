@@ -500,8 +500,8 @@ def test_rows_attention_path_matches_torch(hw):
     assert zerr < 0.08, f"layer err {zerr}"
 
 
-@pytest.mark.parametrize("hw,batch", [(252, 13), (256, 8), (200, 5), (132, 3)])
-def test_qkv_attention_one_launch_matches_three_launch_form_and_torch(hw, batch):
+@pytest.mark.parametrize("hw,batch,qscale", [(252, 13, 1.0), (256, 8, 1.0), (200, 5, 1.0), (132, 3, 1.0), (252, 4, 60.0)])
+def test_qkv_attention_one_launch_matches_three_launch_form_and_torch(hw, batch, qscale):
     """qkv_attn_kernel (LayerNorm1 + QKV + attention per sample and head pair, Q / K / V never in memory) + proj_ffn_rows
     against the qkv_rows -> attn_core -> proj_ffn_rows form and nn.TransformerEncoderLayer(norm_first=True) in fp32."""
     from alphatriangle_amd.ops import hipbind as hb
@@ -526,8 +526,9 @@ def test_qkv_attention_one_launch_matches_three_launch_form_and_torch(hw, batch)
     b_in = layer.self_attn.in_proj_bias.detach().float().clone()
     b_in = b_in + w_in @ be1  # LayerNorm1's affine part folded into the projection, as the engine does
     w_in = w_in * g1[None, :]
-    w_in[:D] *= math.log2(math.e) / math.sqrt(32)
-    b_in[:D] *= math.log2(math.e) / math.sqrt(32)
+    # qscale > 1: scores far outside exp2's range, which sends the kernel through its max-subtracting second pass
+    w_in[:D] *= qscale * math.log2(math.e) / math.sqrt(32)
+    b_in[:D] *= qscale * math.log2(math.e) / math.sqrt(32)
     b_in = b_in.contiguous()
     xb = x.to(torch.bfloat16).contiguous()
     q, k, att = torch.zeros_like(xb), torch.zeros_like(xb), torch.zeros_like(xb)
@@ -546,11 +547,18 @@ def test_qkv_attention_one_launch_matches_three_launch_form_and_torch(hw, batch)
                 hb.i32(heads), hb.i32(Fd), hb.i32(1))
         torch.cuda.synchronize()
         outs[name] = z.float()
-    e1 = (outs["atri_layer_rows"] - ref).abs().max().item()
-    e3 = (outs["atri_layer_rows_unfused"] - ref).abs().max().item()
-    assert e3 < 0.1, e3
-    assert e1 < max(0.1, 1.5 * e3), (e1, e3)
-    assert (outs["atri_layer_rows"] - outs["atri_layer_rows_unfused"]).abs().max().item() < 0.1
+    assert torch.isfinite(outs["atri_layer_rows"]).all()
+    if qscale == 1.0:
+        e1 = (outs["atri_layer_rows"] - ref).abs().max().item()
+        e3 = (outs["atri_layer_rows_unfused"] - ref).abs().max().item()
+        assert e3 < 0.1, e3
+        assert e1 < max(0.1, 1.5 * e3), (e1, e3)
+        assert (outs["atri_layer_rows"] - outs["atri_layer_rows_unfused"]).abs().max().item() < 0.1
+    else:
+        # near one-hot attention: bf16 rounding of Q / K decides near ties, so the two kernels (same roundings) are
+        # compared with each other; almost every element must agree closely
+        diff = (outs["atri_layer_rows"] - outs["atri_layer_rows_unfused"]).abs()
+        assert (diff > 0.1).float().mean().item() < 0.01, (diff > 0.1).float().mean().item()
 
 
 _ODD_CONFIGS = {
