@@ -188,6 +188,63 @@ struct AttnBlockArgs {
   float ln_eps;
 };
 
+// The query tiles of one head (wave) of attn_body: scores key-major from register fragments, softmax, P.V, result rows
+// into the ao tile.  SAFE subtracts the row maxima before exp2; the other form leaves range checking of the
+// denominators to the caller (returned: true when a lane saw one out of range).
+template <bool FULL8, bool SAFE>
+__device__ __forceinline__ bool attn_tiles(const short8 (&Kf)[8], const short8 (&Qf)[8], const short8 (&VTf)[4][2],
+                                           unsigned char* ao, int HW, int n_qt, int wave, int q4, int l15) {
+  const int kt_full = FULL8 ? 7 : HW >> 4;  // key tiles below this index hold no padding
+  const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
+  bool suspect = false;
+#pragma unroll
+  for (int qt = 0; qt < 8; ++qt) {
+    if (qt >= n_qt) break;
+    __builtin_amdgcn_sched_barrier(0);  // keep q-tiles from interleaving: each holds 32 score registers
+    float4v st[8];
+    float m = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt], Qf[qt], (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      if (kt >= kt_full) {  // wave-uniform: only the last (partial) key tile and the all-padding tiles pay for masking
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
+      }
+      if (SAFE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
+      }
+    }
+    if (SAFE) m = quad_row_max(m);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st[kt][j] = __builtin_amdgcn_exp2f(SAFE ? st[kt][j] - m : st[kt][j]);  // scores arrive in log2 units
+    // O^T = V^T P^T, and the softmax denominators come out of the same MFMA pass: a ones fragment as a third
+    // "V^T" tile makes every row of that tile the column sums of P^T (the matrix core is idle enough to take
+    // the 32 adds + 2 shuffles per query tile off the VALU; the sums are over the bf16 P that P.V really uses)
+    float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f}, os = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const short8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][0], pf, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][1], pf, o1, 0, 0, 0);
+      os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
+    }
+    if (!SAFE) suspect |= !(os[0] > 0x1p-100f && os[0] < 0x1p100f);
+    const float inv = __builtin_amdgcn_rcpf(os[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o0[j] *= inv;
+      o1[j] *= inv;
+    }
+    // lane holds channels wave*32 + q4*8 .. +7 of query qt*16 + l15
+    *reinterpret_cast<short8*>(ao + (qt * 16 + l15) * kStride + wave * 64 + q4 * 16) = pack8(o0, o1);
+  }
+  return suspect;
+}
+
 // DBG != 0 instantiations are roofline probes (bench/attn_probe.py), bit mask: 1 no LayerNorm, 2 no K/V/Q GEMMs,
 // 4 no attention loop, 8 no output projection, 16 no input staging, 32 no output stores.
 // Attention half of the layer for sample b: leaves y = x + OutProj(MHA(LayerNorm1(x))) in registers, lane layout
@@ -264,52 +321,13 @@ __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char*
     for (int t = 0; t < 8; ++t) Qf[t] = pack8(acc[t][0], acc[t][1]);
   }
   load_wfrags(wb, reinterpret_cast<const short8*>(a.wo) + (size_t)wave * 128 + lane);  // out-proj weights fly during attention
-  // ---- attention of head `wave`, one 16-query tile at a time
+  // ---- attention of head `wave`, one 16-query tile at a time.  Softmax is shift invariant and bf16 has fp32's exponent
+  // range, so the first pass skips the row maximum (no max, no subtraction: a quarter of the loop's VALU work) and
+  // checks the denominators instead; a wave that saw one outside [2^-100, 2^100] (overflow, total underflow, NaN)
+  // repeats its tiles with the maximum subtracted and overwrites its part of the ao tile.
   const int n_qt = (DBG & 4) ? 0 : (FULL8 ? 8 : (HW + 15) >> 4);
-  const int kt_full = FULL8 ? 7 : HW >> 4;  // key tiles below this index hold no padding
-  const short8 ones = (short8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
-#pragma unroll
-  for (int qt = 0; qt < 8; ++qt) {
-    if (qt >= n_qt) break;
-    __builtin_amdgcn_sched_barrier(0);  // keep q-tiles from interleaving: each holds 32 score registers
-    float4v st[8];
-    float m = -1e30f;
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
-      st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt], Qf[qt], (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      if (kt >= kt_full) {  // wave-uniform: only the last (partial) key tile and the all-padding tiles pay for masking
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
-    }
-    m = quad_row_max(m);
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) st[kt][j] = __builtin_amdgcn_exp2f(st[kt][j] - m);  // scores arrive in log2 units
-    // O^T = V^T P^T, and the softmax denominators come out of the same MFMA pass: a ones fragment as a third
-    // "V^T" tile makes every row of that tile the column sums of P^T (the matrix core is idle enough to take
-    // the 32 adds + 2 shuffles per query tile off the VALU; the sums are over the bf16 P that P.V really uses)
-    float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f}, os = (float4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const short8 pf = pack8(st[2 * kb], st[2 * kb + 1]);
-      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][0], pf, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VTf[kb][1], pf, o1, 0, 0, 0);
-      os = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, os, 0, 0, 0);
-    }
-    const float inv = __builtin_amdgcn_rcpf(os[0]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      o0[j] *= inv;
-      o1[j] *= inv;
-    }
-    // lane holds channels wave*32 + q4*8 .. +7 of query qt*16 + l15
-    *reinterpret_cast<short8*>(ao + (qt * 16 + l15) * kStride + wave * 64 + q4 * 16) = pack8(o0, o1);
-  }
+  const bool suspect = attn_tiles<FULL8, false>(Kf, Qf, VTf, ao, HW, n_qt, wave, q4, l15);
+  if (__builtin_amdgcn_ballot_w64(suspect) != 0) (void)attn_tiles<FULL8, true>(Kf, Qf, VTf, ao, HW, n_qt, wave, q4, l15);
   __syncthreads();
 
   // ---- output projection + residual
