@@ -77,11 +77,12 @@ __device__ __forceinline__ void layernorm_rows(unsigned char* lds, int HW, const
   const float rstd = rsqrtf(fmaxf(ss * (1.0f / kD) - mean * mean, 0.f) + eps);
   if (live) {
     if (g == nullptr) {  // affine part folded into the following GEMM's weights and bias by the host
+      const float shift = -mean * rstd;  // one fma per element
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16_to_float((unsigned short)v[c][j]) - mean) * rstd;
+        for (int j = 0; j < 8; ++j) o[j] = bf16_to_float((unsigned short)v[c][j]) * rstd + shift;
         *reinterpret_cast<short8*>(rowp + c * 16) = pack_bf16x8(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
       }
     } else {
