@@ -1,0 +1,50 @@
+"""bench.py's output contract: exactly one JSON line on stdout with the fields the benchmark driver reads."""
+
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config"}
+
+
+def _run(args: list[str], timeout: int = 300) -> subprocess.CompletedProcess:
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_bench_without_gpu_reports_one_json_error_line():
+    res = _run(["--steps", "1", "--warmup", "0"])
+    assert res.returncode == 1
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    assert "error" in json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_prints_exactly_one_json_line_with_the_contract_fields():
+    res = _run(["--steps", "2", "--warmup", "1", "--games", "512", "--sims", "16", "--train-steps", "2"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert REQUIRED <= set(out)
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["dtype"] == "bf16"
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    # value = games * steps / elapsed: consistent with the per-step time it reports
+    assert abs(out["value"] - 512 / (out["ms_per_step"] / 1e3)) / out["value"] < 0.02
+    assert {"model", "global_batch", "seq_len", "parallelism"} <= set(out["config"])
+    assert out["trainer_samples_per_sec"] > 0
