@@ -67,6 +67,32 @@ class FlatParameterSpace:
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
 
+    def release_grads(self) -> None:
+        """Detach ``p.grad`` from the flat buffer so that autograd hands each parameter its gradient tensor as it is.
+
+        Accumulating into the views costs one small add kernel per parameter and step (70 of them for the default
+        network); with ``p.grad = None`` autograd just stores the tensor it computed and :meth:`gather_grads` moves
+        all of them into the flat buffer with one multi-tensor copy.
+        """
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self) -> None:
+        """Copy the gradients autograd left in ``p.grad`` into the flat buffer and re-attach the views."""
+        views = self.view_like_params(self.flat_grad)
+        src, dst = [], []
+        with torch.no_grad():
+            for p, v in zip(self.params, views, strict=True):
+                if p.grad is None:
+                    v.zero_()  # parameter took no part in this step
+                elif p.grad.data_ptr() != v.data_ptr():
+                    src.append(p.grad)
+                    dst.append(v)
+            if src:
+                torch._foreach_copy_(dst, src)
+            for p, v in zip(self.params, views, strict=True):
+                p.grad = v
+
     def view_like_params(self, flat: torch.Tensor) -> list[torch.Tensor]:
         return [flat[off : off + p.numel()].view(p.shape) for p, off in zip(self.params, self.offsets, strict=True)]
 

@@ -257,7 +257,10 @@ class Trainer:
     # ------------------------------------------------------------------ the step
     def _forward_backward(self, tb: TensorBatch) -> LossOutputs:
         """Zero the gradients, run forward + loss + backward; gradients end up in ``p.grad`` / the flat buffer."""
-        self.optimizer.zero_grad()
+        if self.flat is not None:
+            self.flat.release_grads()  # every gradient is written, not accumulated: no zeroing, no per-parameter adds
+        else:
+            self.optimizer.zero_grad()
         if self.autocast_bf16:
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
                 policy_logits, value_logits = self.model(tb.grid, tb.other)
@@ -276,6 +279,8 @@ class Trainer:
             entropy_weight=self.train_config.ENTROPY_BONUS_WEIGHT,
         )
         out.total.backward()
+        if self.flat is not None:
+            self.flat.gather_grads()
         return out
 
     def _graph_for(self, tb: TensorBatch) -> GraphedForwardBackward | None:
