@@ -114,8 +114,10 @@ class _ConvGemmCM(torch.autograd.Function):
         cout, _, kh, kw = weight.shape
         if kh == 1 and kw == 1:
             cols = x.reshape(cin, b * h * w)
-        else:
+        elif x.is_cuda:
             cols = hip_learner.patch_matrix_cm(x, kh, kw, ph, pw)
+        else:  # host tensors (tests of the channel-major plumbing): strided-view gather
+            cols = _patch_matrix(x.permute(1, 0, 2, 3), kh, kw, ph, pw)
         ctx.save_for_backward(cols, weight)
         ctx.geom = (b, h, w, ph, pw)
         oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
@@ -141,7 +143,10 @@ class _ConvGemmCM(torch.autograd.Function):
             if kh == 1 and kw == 1:
                 d_x = (weight.reshape(cout, cin).t() @ g.view(cout, -1)).view(cin, b, h, w)
             else:
-                g_cols = hip_learner.patch_matrix_cm(g, kh, kw, kh - 1 - ph, kw - 1 - pw)  # [Cout*kh*kw, B*H*W]
+                if g.is_cuda:
+                    g_cols = hip_learner.patch_matrix_cm(g, kh, kw, kh - 1 - ph, kw - 1 - pw)  # [Cout*kh*kw, B*H*W]
+                else:
+                    g_cols = _patch_matrix(g.permute(1, 0, 2, 3), kh, kw, kh - 1 - ph, kw - 1 - pw)
                 w_t = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * kh * kw)
                 d_x = (w_t @ g_cols).view(cin, b, h, w)
         return d_x, d_w, None, None
@@ -530,17 +535,21 @@ class AlphaTriangleNet(nn.Module):
             return mod.activation(y + x)
         return mod(x)  # activations and Identity are layout-agnostic
 
+    def body_channel_major(self, grid_state: torch.Tensor) -> torch.Tensor:
+        """:meth:`body` with the convolution body on channel-major activations (same result, no layout copies)."""
+        x = grid_state.permute(1, 0, 2, 3)  # [C, B, H, W]: a view for the usual single input channel
+        x = self._cm_apply(self.res_body, self._cm_apply(self.conv_body, x))
+        if self.uses_transformer and self.transformer_body is not None and self.pos_encoder is not None:
+            x = self._cm_apply(self.input_proj, x)
+            tokens = x.flatten(2).permute(2, 1, 0).contiguous()  # [H*W, B, D]
+            tokens = self.transformer_body(self.pos_encoder(tokens))
+            return tokens.permute(1, 0, 2).flatten(1)
+        return x.permute(1, 0, 2, 3).reshape(x.size(1), -1)
+
     def body(self, grid_state: torch.Tensor) -> torch.Tensor:
         """Feature extractor up to (and excluding) the shared FC: returns ``[B, feat]``."""
         if self._cm_plan_ok(grid_state):
-            x = grid_state.permute(1, 0, 2, 3)  # [C, B, H, W]: a view for the usual single input channel
-            x = self._cm_apply(self.res_body, self._cm_apply(self.conv_body, x))
-            if self.uses_transformer and self.transformer_body is not None and self.pos_encoder is not None:
-                x = self._cm_apply(self.input_proj, x)
-                tokens = x.flatten(2).permute(2, 1, 0).contiguous()  # [H*W, B, D]
-                tokens = self.transformer_body(self.pos_encoder(tokens))
-                return tokens.permute(1, 0, 2).flatten(1)
-            return x.permute(1, 0, 2, 3).reshape(x.size(1), -1)
+            return self.body_channel_major(grid_state)
         x = self.res_body(self.conv_body(grid_state))
         if self.uses_transformer and self.transformer_body is not None and self.pos_encoder is not None:
             x = self.input_proj(x)

@@ -121,3 +121,45 @@ def test_encoder_layer_fast_path_matches_stock_layer(act):
     assert list(stock.state_dict().keys()) == list(layer.state_dict().keys())
     # CPU tensors and masked calls use the stock implementation
     assert not layer._fast_ok(x, None, None, False)
+
+
+@pytest.mark.parametrize("use_transformer", [False, True])
+@pytest.mark.parametrize("residual_filters", [16, 24])
+def test_channel_major_body_equals_nchw_body_on_cpu(use_transformer: bool, residual_filters: int):
+    """The learner's channel-major convolution body (activations [C, B, H, W], BatchNorm on a one-image view) must give
+    the NCHW body's features, gradients and BatchNorm running statistics (fp32 on the host: equal up to summation order).
+    24 residual filters after a 16-filter stem also exercise the 1x1 projection."""
+    import copy
+
+    from alphatriangle_amd.config import EnvConfig, ModelConfig
+    from alphatriangle_amd.models.model import AlphaTriangleNet
+
+    torch.manual_seed(11)
+    env = EnvConfig(ROWS=4, COLS=6, PLAYABLE_RANGE_PER_ROW=[(0, 6)] * 4, NUM_SHAPE_SLOTS=1)
+    mc = ModelConfig(
+        CONV_FILTERS=[8, 16], CONV_KERNEL_SIZES=[3, 3], CONV_STRIDES=[1, 1], CONV_PADDING=[1, 1], NUM_RESIDUAL_BLOCKS=1,
+        RESIDUAL_BLOCK_FILTERS=residual_filters, USE_TRANSFORMER=use_transformer, TRANSFORMER_DIM=16, TRANSFORMER_HEADS=2,
+        TRANSFORMER_LAYERS=1 if use_transformer else 0, TRANSFORMER_FC_DIM=32, FC_DIMS_SHARED=[16], POLICY_HEAD_DIMS=[16],
+        VALUE_HEAD_DIMS=[16], OTHER_NN_INPUT_FEATURES_DIM=14,
+    )
+    net_a = AlphaTriangleNet(mc, env).double().train()
+    for m in net_a.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0  # applied functionally inside the attention
+    net_b = copy.deepcopy(net_a)
+    grid = torch.randint(-1, 2, (5, 1, env.ROWS, env.COLS)).double()
+    fa = net_a.body_channel_major(grid)
+    fb = net_b.body(grid)
+    assert fa.shape == fb.shape
+    assert torch.allclose(fa, fb, atol=1e-9)
+    fa.square().sum().backward()
+    fb.square().sum().backward()
+    for (name, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        if pb.grad is None:
+            assert pa.grad is None, name
+            continue
+        assert torch.allclose(pa.grad, pb.grad, atol=1e-8), name
+    for (name, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.allclose(ba.double(), bb.double(), atol=1e-10), name
