@@ -90,8 +90,11 @@ def test_worker_runs_an_episode(tiny, tmp_path):
     for state, policy, ret in res.episode_experiences:
         assert state["grid"].shape == (1, 4, 5) and state["other_features"].shape == (22,)
         assert len(policy) == env.ACTION_DIM and abs(sum(policy.values()) - 1.0) < 1e-6 and np.isfinite(ret)
-    # last experience: its only reward is the terminal one (alive bonus replaced by the game-over penalty)
-    assert res.episode_experiences[-1][2] < -9.0
+    # last experience: no bootstrap, its return is exactly the reward of the terminal move (placement / clearing reward
+    # plus the game-over penalty that replaces the alive bonus)
+    last_reward = [e.value for e in sink.events if e.name == "step_reward"][-1]
+    assert abs(res.episode_experiences[-1][2] - last_reward) < 1e-6
+    assert last_reward < 0.0
     names = {e.name for e in sink.events}
     assert {"mcts_step", "step_reward", "current_score", "episode_end"} <= names
     end = [e for e in sink.events if e.name == "episode_end"][0]
