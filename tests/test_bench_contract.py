@@ -48,3 +48,8 @@ def test_bench_prints_exactly_one_json_line_with_the_contract_fields():
     assert abs(out["value"] - 512 / (out["ms_per_step"] / 1e3)) / out["value"] < 0.02
     assert {"model", "global_batch", "seq_len", "parallelism"} <= set(out["config"])
     assert out["trainer_samples_per_sec"] > 0
+
+
+def test_bench_metric_string_is_the_one_baseline_json_names():
+    metric = json.loads((ROOT / "BASELINE.json").read_text())["metric"]
+    assert f'"metric": "{metric}"' in (ROOT / "bench.py").read_text()
