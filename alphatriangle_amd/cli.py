@@ -78,9 +78,23 @@ def train(
     data_root: Annotated[str | None, typer.Option(help="Root directory for run data (default .trieye_data).")] = None,
     layout: Annotated[str, typer.Option(help="Multi-GPU role layout: colocated (every rank plays and learns) or split (actor ranks + learner ranks).")] = "colocated",
     learners: Annotated[int, typer.Option(help="Learner ranks of the split layout (the rest self-play).")] = 1,
-    train_steps_per_round: Annotated[int | None, typer.Option(help="Split layout: learner steps per self-play move round.")] = None,
+    train_steps_per_round: Annotated[int | None, typer.Option(help="Split layout: learner steps between two polls for shipments and weight requests.")] = None,
+    gpus: Annotated[int, typer.Option(help="Number of GPUs of this node to use: one process per GPU, started by this command.")] = 1,
+    dtype: Annotated[str | None, typer.Option(help="Leaf-evaluation precision of the GPU engine: fp32 (reference precision) or bf16 (fast).")] = None,
+    dist_backend: Annotated[str, typer.Option(help="Process-group backend: auto, nccl (= RCCL) or gloo (CPU rehearsals).")] = "auto",
 ) -> None:
-    """Run the headless training pipeline (one process per GPU; launch under torchrun for several GPUs)."""
+    """Run the headless training pipeline.  `--gpus N` starts N ranks (one per GPU) from this one command."""
+    from .parallel.launch import launch_local_ranks, under_launcher, world_size_from_env
+
+    if gpus < 1:
+        raise typer.BadParameter("--gpus must be at least 1")
+    if not under_launcher():
+        if gpus > 1:
+            # no GPU call has been made in this process: start one fresh child per GPU and wait for them
+            sys.exit(launch_local_ranks(gpus, [sys.executable, "-m", "alphatriangle_amd", *sys.argv[1:]]))
+    elif gpus != world_size_from_env() and gpus != 1:
+        raise typer.BadParameter(f"--gpus {gpus} does not match WORLD_SIZE={world_size_from_env()} of the launcher")
+
     from .parallel.dist import init_from_env
     from .presets import build_preset
     from .training.runner import run_training
@@ -104,6 +118,13 @@ def train(
     sys_cfg.NUM_LEARNER_RANKS = learners
     if train_steps_per_round is not None:
         sys_cfg.TRAIN_STEPS_PER_ROUND = train_steps_per_round
+    if dtype is not None:
+        if dtype not in ("fp32", "bf16"):
+            raise typer.BadParameter("--dtype must be 'fp32' or 'bf16'")
+        sys_cfg.INFERENCE_DTYPE = dtype  # type: ignore[assignment]
+    if dist_backend not in ("auto", "nccl", "gloo"):
+        raise typer.BadParameter("--dist-backend must be auto, nccl or gloo")
+    sys_cfg.DIST_BACKEND = dist_backend  # type: ignore[assignment]
 
     trieye_cfg = TrieyeConfig(app_name=APP_NAME, run_name=run_name or train_cfg.RUN_NAME)
     train_cfg.RUN_NAME = trieye_cfg.run_name

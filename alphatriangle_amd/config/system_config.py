@@ -24,27 +24,43 @@ class SystemConfig(BaseModel):
     GAMES_PER_GPU: int = Field(default=4096, ge=1, description="Concurrent self-play games per actor GPU.")
     LEAVES_PER_TREE: int = Field(default=1, ge=1, le=32, description="Leaves per tree per wave (virtual loss if >1).")
     TREE_REUSE: bool = Field(default=True)
-    INFERENCE_DTYPE: Literal["bf16"] = Field(default="bf16")
-    LEARNER_AUTOCAST: bool = Field(default=True, description="bf16 autocast for the learner forward/backward.")
-    REPLAY_ON_DEVICE: bool = Field(default=True, description="Keep the replay buffer in HBM on GPU runs.")
+    INFERENCE_DTYPE: Literal["fp32", "bf16"] = Field(
+        default="fp32",
+        description="Precision of the leaf evaluations that drive the search. fp32: fp32 activations, every GEMM as three "
+        "bf16 MFMA passes over (hi, lo) operand splits with fp32 accumulation (the reference evaluates in fp32); "
+        "bf16: bf16 activations and single-pass MFMA (about twice as fast).",
+    )
+    LEARNER_AUTOCAST: bool | None = Field(
+        default=None,
+        description="bf16 autocast for the learner forward/backward; None follows INFERENCE_DTYPE (off for fp32).",
+    )
     REPLAY_HBM_BUDGET_GB: float = Field(default=64.0, gt=0)
     TRAIN_STEPS_PER_MOVE: int = Field(default=1, ge=0, description="Learner steps interleaved per self-play move.")
     TRAIN_STEPS_PER_ROUND: int = Field(
-        default=32, ge=0,
-        description="Split layout: learner steps per lock-step round (one round = one self-play move on every actor rank).",
+        default=8, ge=1,
+        description="Split layout: learner steps between two polls of the control store (shipments, weight requests).",
     )
-    SHIP_CAPACITY: int = Field(default=1 << 15, ge=1, description="Split layout: experience records per actor per round (fixed block).")
+    SHIP_CAPACITY: int = Field(default=1 << 15, ge=1, description="Split layout: upper bound of experience records in one shipment.")
+    MAX_SAMPLE_REUSE: float | None = Field(
+        default=None, gt=0,
+        description="Split layout: the learner consumes at most this many samples per experience received (replay ratio); None = no limit.",
+    )
+    ACTOR_SILENCE_S: float = Field(default=300.0, gt=0, description="Split layout: an actor rank that ships nothing for this long is retired.")
+    COLLECTIVE_TIMEOUT_S: float = Field(default=120.0, gt=0, description="Time-out of every data-plane collective (RCCL / gloo).")
+    CONTROL_TIMEOUT_S: float = Field(default=60.0, gt=0, description="Time-out of the host-side control plane (agreements, drains).")
     OVERLAP_LEARNER: bool = Field(
         default=True, description="Colocated GPU runs: learner steps on a second HIP stream, concurrent with the search of the move."
     )
     USE_HIP_GRAPHS: bool = Field(default=True)
-    WEIGHT_SYNC_ASYNC: bool = Field(default=True)
     DIST_BACKEND: Literal["auto", "nccl", "gloo"] = Field(default="auto", description="nccl = RCCL on ROCm.")
     TEMPERATURE_SWITCH_GAME_STEP: int | None = Field(
         default=None,
         description="Game step after which action selection uses temperature 0.1; None keeps the reference rule "
         "(10% of MAX_TRAINING_STEPS).",
     )
+
+    def learner_autocast(self) -> bool:
+        return self.INFERENCE_DTYPE == "bf16" if self.LEARNER_AUTOCAST is None else bool(self.LEARNER_AUTOCAST)
 
     @model_validator(mode="after")
     def _check(self) -> "SystemConfig":

@@ -43,8 +43,13 @@ struct TreeBufs {
   const float* nn_logits;  // [G*L][logit_stride]
   const float* nn_value;   // [G*L]
   int32_t* order;      // [G][C] scratch for re-rooting
+  // per-tree counters, private to the tree's wave (plain read-modify-write, summed on the host once per move):
+  // [0..3] leaf slots by kind (none / expand / terminal / depth cap), [4] network evaluations that were not finite
+  int32_t* census;     // [G][kCensus]
   int32_t G, C, A, L, P, other_dim, logit_stride, pad;
 };
+constexpr int kCensus = 8;
+constexpr int kCensusNonFinite = 4;
 
 __device__ __forceinline__ State* tree_states(const TreeBufs& tb, int g) { return tb.states[tb.cur[g]] + (size_t)g * tb.C; }
 __device__ __forceinline__ NodeMeta* tree_meta(const TreeBufs& tb, int g) { return tb.meta[tb.cur[g]] + (size_t)g * tb.C; }
@@ -122,8 +127,13 @@ __device__ void wave_features(const GeomView& g, const State& st, float* grid, f
 // Masked softmax of the network logits over the valid actions (wave order) -> fresh edges.
 // For action spaces up to 6 x 64 the per-lane validity bits and exponentials are computed once and kept
 // in registers across the max / sum / write passes (the arithmetic and its order are unchanged).
+// Finite guard (the reference checks every evaluation: alphatriangle/nn/network.py:177-191,260-274): a NaN or an
+// infinity among the logits of the valid actions makes the softmax denominator non-finite.  Such a node gets a uniform
+// prior over its valid actions - a NaN prior would fail every PUCT comparison and freeze the tree - and the
+// function returns true so that the caller counts the evaluation; the host raises after the move.  For finite logits
+// neither the arithmetic nor its order changes.
 constexpr int kLaneActs = 6;
-__device__ void wave_init_edges(const GeomView& g, const State& st, Edge* ed, const float* logits, int lane) {
+__device__ bool wave_init_edges(const GeomView& g, const State& st, Edge* ed, const float* logits, int lane) {
   if (g.action_dim <= kLaneActs * 64) {
     float lg[kLaneActs];
     unsigned vbits = 0;
@@ -152,19 +162,22 @@ __device__ void wave_init_edges(const GeomView& g, const State& st, Edge* ed, co
       }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+    const bool bad = !(s > 0.0f && s < INFINITY);  // wave-uniform
+    float uni = 0.0f;
+    if (bad) uni = 1.0f / (float)max(1, atrihip::wave_sum_i(__popc(vbits)));
 #pragma unroll
     for (int k = 0; k < kLaneActs; ++k) {
       const int a = lane + 64 * k;
       if (a < g.action_dim) {
         Edge e;
-        e.prior = (vbits & (1u << k)) ? lg[k] / s : -1.0f;
+        e.prior = (vbits & (1u << k)) ? (bad ? uni : lg[k] / s) : -1.0f;
         e.n = 0;
         e.w = 0.0f;
         e.child = -1;
         ed[a] = e;
       }
     }
-    return;
+    return bad;
   }
   float mx = -INFINITY;
   for (int a = lane; a < g.action_dim; a += 64)
@@ -175,14 +188,22 @@ __device__ void wave_init_edges(const GeomView& g, const State& st, Edge* ed, co
     if (action_valid(g, st, a)) s = s + exp_det(logits[a] - mx);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+  const bool bad = !(s > 0.0f && s < INFINITY);
+  float uni = 0.0f;
+  if (bad) {
+    int nv = 0;
+    for (int a = lane; a < g.action_dim; a += 64) nv += action_valid(g, st, a) ? 1 : 0;
+    uni = 1.0f / (float)max(1, atrihip::wave_sum_i(nv));
+  }
   for (int a = lane; a < g.action_dim; a += 64) {
     Edge e;
-    e.prior = action_valid(g, st, a) ? exp_det(logits[a] - mx) / s : -1.0f;
+    e.prior = action_valid(g, st, a) ? (bad ? uni : exp_det(logits[a] - mx) / s) : -1.0f;
     e.n = 0;
     e.w = 0.0f;
     e.child = -1;
     ed[a] = e;
   }
+  return bad;
 }
 
 // PUCT argmax over a node's edges: lanes stride over the dense edge array, xor-butterfly reduction with
@@ -356,11 +377,17 @@ __global__ void init_roots_kernel(GeomView g, TreeBufs tb, SearchParams sp, uint
   Edge* ed = tree_edges(tb, t);
   const State st = tree_states(tb, t)[0];
   if (tb.slot_kind[slot] == kSlotExpand) {
-    wave_init_edges(g, st, ed, tb.nn_logits + (size_t)slot * tb.logit_stride, lane);
+    bool bad = wave_init_edges(g, st, ed, tb.nn_logits + (size_t)slot * tb.logit_stride, lane);
     if (lane == 0) {
       NodeMeta m = mt[0];
       m.expanded = 1;
-      m.nn_value = tb.nn_value[slot];
+      float v = tb.nn_value[slot];
+      if (!(fabsf(v) < INFINITY)) {
+        bad = true;
+        v = 0.0f;
+      }
+      if (bad) tb.census[(size_t)t * kCensus + kCensusNonFinite] += 1;
+      m.nn_value = v;
       m.n = 1;
       m.w = m.nn_value;
       mt[0] = m;
@@ -412,8 +439,13 @@ __global__ void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int d
       float value = 0.0f;
       if (kind == kSlotExpand) {
         const State st = states[leaf];
-        wave_init_edges(g, st, edges + (size_t)leaf * A, tb.nn_logits + (size_t)slot * tb.logit_stride, lane);
+        bool bad = wave_init_edges(g, st, edges + (size_t)leaf * A, tb.nn_logits + (size_t)slot * tb.logit_stride, lane);
         value = tb.nn_value[slot];
+        if (!(fabsf(value) < INFINITY)) {
+          bad = true;
+          value = 0.0f;
+        }
+        if (bad && lane == 0) tb.census[(size_t)t * kCensus + kCensusNonFinite] += 1;
       } else if (kind == kSlotDepthCap) {
         value = meta[leaf].nn_value;
       }
@@ -563,6 +595,7 @@ __global__ void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int d
       tb.slot_kind[slot] = kind;
       tb.slot_leaf[slot] = leaf;
       tb.slot_plen[slot] = plen;
+      tb.census[(size_t)t * kCensus + kind] += 1;
     }
     __syncthreads();
   }
@@ -610,6 +643,11 @@ struct GameBufs {
   int32_t* reroot_child;  // [G] node index of the chosen child, -1 = fresh tree
   int32_t* chosen_action; // [G]
   const float* gamma_pow; // [n_step+1]
+  // what this move did to each game (one metric sample per game step on the host): reward (NaN = the game did not
+  // move in this call), triangles cleared, score after the move
+  float* step_reward;     // [G]
+  float* step_cleared;    // [G]
+  float* step_score;      // [G]
   uint64_t base_seed;
   int32_t R, n_step, cap, emit_cap, ep_ring, temp_switch_step, tree_reuse, reuse_limit;
   float temp_hi, temp_lo;
@@ -650,6 +688,9 @@ __global__ void commit_moves_kernel(GeomView g, TreeBufs tb, GameBufs gb) {
       gb.chosen_action[t] = -1;
       gb.pend_len[t] = 0;
       gb.ep_sims[t] = 0;
+      gb.step_reward[t] = NAN;
+      gb.step_cleared[t] = 0.0f;
+      gb.step_score[t] = 0.0f;
     }
     return;
   }
@@ -804,6 +845,9 @@ __global__ void commit_moves_kernel(GeomView g, TreeBufs tb, GameBufs gb) {
   if (lane == 0) {
     gb.game_rng[t] = rng;
     gb.chosen_action[t] = action;
+    gb.step_reward[t] = reward;
+    gb.step_cleared[t] = (float)cleared;
+    gb.step_score[t] = st.score;
     const int sims = gb.ep_sims[t] + total;
     atomicAdd(&gb.move_stats[0], reward);
     atomicAdd(&gb.move_stats[1], (float)cleared);

@@ -43,6 +43,7 @@ class NeuralNetwork:
         train_config: TrainConfig,
         device: torch.device,
         use_hip_engine: bool | None = None,
+        inference_dtype: str = "bf16",
     ):
         self.model_config = model_config
         self.env_config = env_config
@@ -67,11 +68,17 @@ class NeuralNetwork:
         if want_engine and self.device.type == "cuda":
             from ..ops.inference import InferenceEngine, engine_supports
 
-            ok, why = engine_supports(model_config, env_config)
+            ok, why = engine_supports(model_config, env_config, inference_dtype)
+            if not ok and inference_dtype != "bf16":
+                ok2, _ = engine_supports(model_config, env_config, "bf16")
+                if ok2:
+                    logger.warning("HIP inference engine has no %s path for this config (%s); its bf16 path is loaded instead.",
+                                   inference_dtype, why)
+                    ok, inference_dtype = True, "bf16"
             if ok:
-                self.engine = InferenceEngine(model_config, env_config, self.device)
+                self.engine = InferenceEngine(model_config, env_config, self.device, dtype=inference_dtype)
                 self.engine.load_from_module(self._orig_model)
-                logger.info("HIP inference engine active (BN-folded bf16 weights).")
+                logger.info("HIP inference engine active (BN folded, %s).", self.engine.dtype)
             else:
                 logger.warning("HIP inference engine not used for this config: %s", why)
 

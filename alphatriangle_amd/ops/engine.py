@@ -32,6 +32,8 @@ STATE_BYTES = 64
 META_BYTES = 32
 EDGE_BYTES = 16
 SLOT_NONE, SLOT_EXPAND, SLOT_TERMINAL, SLOT_DEPTHCAP = 0, 1, 2, 3
+CENSUS_WIDTH = 8       # per-tree counters: [0..3] leaf slots by kind, [4] non-finite network evaluations
+CENSUS_NON_FINITE = 4
 
 
 class GpuTreeEngine:
@@ -85,6 +87,7 @@ class GpuTreeEngine:
             np.random.default_rng(seed ^ 0x5EED).integers(1, 2**62, size=G, dtype=np.int64)
         ).to(dev)
         self.root_states = torch.zeros(G, STATE_BYTES, dtype=torch.uint8, device=dev)
+        self.census = torch.zeros(G, CENSUS_WIDTH, dtype=torch.int32, device=dev)
 
         tb = hb.TreeBufsC()
         for a in range(2):
@@ -103,6 +106,7 @@ class GpuTreeEngine:
         tb.nn_logits = self.logits.data_ptr()
         tb.nn_value = self.values.data_ptr()
         tb.order = self.order.data_ptr()
+        tb.census = self.census.data_ptr()
         tb.G, tb.C, tb.A, tb.L, tb.P = G, Cn, A, L, self.P
         tb.other_dim = self.other_dim
         tb.logit_stride = int(self.logits.stride(0))
@@ -150,6 +154,10 @@ class GpuTreeEngine:
 
     def wave(self, consume: bool, select: bool) -> None:
         hb.call("atri_tree_wave", self.geom.ref(), C.byref(self.tb), C.byref(self.sp), hb.i32(1 if consume else 0), hb.i32(1 if select else 0))
+
+    def census_totals(self) -> torch.Tensor:
+        """Per-kind leaf-slot counts and the non-finite evaluation count summed over all trees (``[CENSUS_WIDTH]`` int64)."""
+        return self.census.sum(dim=0, dtype=torch.int64)
 
     def root_visits(self) -> torch.Tensor:
         out = torch.zeros(self.G, self.A, dtype=torch.int32, device=self.device)
@@ -211,6 +219,7 @@ class GpuTreeEngine:
         self.reroot_child = torch.zeros(G, dtype=torch.int32, device=dev)
         self.chosen_action = torch.zeros(G, dtype=torch.int32, device=dev)
         self.gamma_pow = torch.tensor([gamma**i for i in range(R + 1)], dtype=torch.float32, device=dev)
+        self.step_out = torch.zeros(3, G, dtype=torch.float32, device=dev)  # rows: reward (NaN = no move), cleared, score
         if replay.emit_capacity < G * R:
             raise ValueError("replay.emit_capacity must be at least games * (n_step + 1)")
         gb = hb.GameBufsC()
@@ -241,6 +250,9 @@ class GpuTreeEngine:
         gb.reroot_child = self.reroot_child.data_ptr()
         gb.chosen_action = self.chosen_action.data_ptr()
         gb.gamma_pow = self.gamma_pow.data_ptr()
+        gb.step_reward = self.step_out[0].data_ptr()
+        gb.step_cleared = self.step_out[1].data_ptr()
+        gb.step_score = self.step_out[2].data_ptr()
         gb.base_seed = int(base_seed) & (2**64 - 1)
         gb.R = R
         gb.n_step = n_step

@@ -77,6 +77,7 @@ class TreeBufsC(C.Structure):
         ("nn_logits", VP),
         ("nn_value", VP),
         ("order", VP),
+        ("census", VP),
         ("G", C.c_int32),
         ("C", C.c_int32),
         ("A", C.c_int32),
@@ -117,6 +118,9 @@ class GameBufsC(C.Structure):
         ("reroot_child", VP),
         ("chosen_action", VP),
         ("gamma_pow", VP),
+        ("step_reward", VP),
+        ("step_cleared", VP),
+        ("step_score", VP),
         ("base_seed", C.c_uint64),
         ("R", C.c_int32),
         ("n_step", C.c_int32),

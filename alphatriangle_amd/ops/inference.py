@@ -54,8 +54,10 @@ def _pow2(x: int) -> bool:
     return x > 0 and (x & (x - 1)) == 0
 
 
-def engine_supports(mc: ModelConfig, ec: EnvConfig) -> tuple[bool, str]:
-    """Whether the HIP engine implements this architecture (else callers use the PyTorch module)."""
+def engine_supports(mc: ModelConfig, ec: EnvConfig, dtype: str = "bf16") -> tuple[bool, str]:
+    """Whether the HIP engine implements this architecture at this precision (else callers use the PyTorch module)."""
+    if dtype not in ("bf16",):
+        return False, f"no {dtype} kernels"
     if mc.GRID_INPUT_CHANNELS != 1:
         return False, "GRID_INPUT_CHANNELS != 1"
     if not mc.CONV_FILTERS:
@@ -189,11 +191,12 @@ def _split_seq(seq: nn.Sequential) -> list[tuple[nn.Module, nn.Module | None, bo
 
 
 class InferenceEngine:
-    def __init__(self, model_config: ModelConfig, env_config: EnvConfig, device: torch.device):
-        ok, why = engine_supports(model_config, env_config)
+    def __init__(self, model_config: ModelConfig, env_config: EnvConfig, device: torch.device, dtype: str = "bf16"):
+        ok, why = engine_supports(model_config, env_config, dtype)
         if not ok:
             raise ValueError(f"HIP inference engine does not support this config: {why}")
         hb.lib()  # fail loudly when the kernel library is missing
+        self.dtype = dtype
         self.mc = model_config
         self.ec = env_config
         self.device = torch.device(device)

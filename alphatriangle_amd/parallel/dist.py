@@ -5,17 +5,27 @@ object store (alphatriangle/training/worker_manager.py:44-45,179-194 broadcast
 weights by ``ray.put`` + N remote calls; :117-134 gather episode results).  The
 equivalents here:
 
-* weights learner -> actors : ONE ``broadcast`` of the flat fp32 parameter buffer
-  (12 MB for the default net), optionally on a side stream into a staging buffer so
-  self-play never waits for the wire;
+* weights learner -> actors : the flat fp32 parameter wire (12 MB for the default net), point to point to
+  each actor over its own xGMI link when the actor asks for a newer version at a move boundary
+  (training/split_loop.py); ``broadcast_weights`` is the collective form for lock-step callers;
 * learner gradients (data parallel) : ONE ``all_reduce`` of the flat gradient buffer
   between backward and the fused optimizer step.  xGMI is point-to-point, so a
   message this small is latency-bound; it is deliberately a single un-bucketed call;
-* experiences actors -> learner : ``all_gather`` of fixed-stride SoA record blocks
-  (parallel/experience.py).
+* experiences actors -> learner : point-to-point sends of exactly the rows a move produced, announced in the
+  control store first (parallel/experience.py).
 
 ``gloo`` (CPU tests, rehearsals) only ever sees CPU tensors: device tensors are
 staged through host memory with synchronous copies.
+
+Control plane.  Decisions (ready to train? stop? how many steps this move?) never ride
+on the RCCL data plane: they go through a host-side channel - a ``gloo`` side group for
+the collective "agree" of data-parallel ranks, and the job's rendezvous key/value store
+(:class:`ControlPlane`) for the asynchronous split layout, where every transfer is
+announced in the store before either side posts it.  A rank that disappears therefore
+shows up as :class:`PeerLostError` within ``control_timeout_s`` (connection reset, or the
+time-out) instead of stranding the others inside a device collective for minutes - the
+reference's manager likewise notices a dead worker and carries on or stops
+(alphatriangle/training/worker_manager.py:153-167).
 """
 
 from __future__ import annotations
@@ -30,6 +40,43 @@ import torch
 import torch.distributed as dist
 
 logger = logging.getLogger(__name__)
+
+
+class PeerLostError(RuntimeError):
+    """A rank of the job stopped answering on the control plane (died, hung, or was killed)."""
+
+
+class ControlPlane:
+    """Host-side key/value channel over the job's rendezvous store (TCP store of rank 0, or a file store in tests).
+
+    Only integers travel: counters (``add``), versions and flags (``put`` / ``peek``).  Nothing here touches the GPU
+    and nothing blocks: a key that does not exist yet reads as ``default``.
+    """
+
+    def __init__(self, store: Any, prefix: str = "atri"):
+        self.store = store
+        self.prefix = prefix
+
+    def _k(self, key: str) -> str:
+        return f"{self.prefix}/{key}"
+
+    def add(self, key: str, amount: int = 1) -> int:
+        return int(self.store.add(self._k(key), int(amount)))
+
+    def counter(self, key: str) -> int:
+        return int(self.store.add(self._k(key), 0))
+
+    def put(self, key: str, value: int) -> None:
+        self.store.set(self._k(key), str(int(value)))
+
+    def peek(self, key: str, default: int | None = None) -> int | None:
+        k = self._k(key)
+        try:
+            if not self.store.check([k]):
+                return default
+            return int(self.store.get(k))
+        except Exception:  # a store whose host went away
+            raise PeerLostError(f"control store unreachable while reading '{key}'") from None
 
 
 @dataclass
@@ -66,12 +113,11 @@ class DistContext:
     layout: RoleLayout
     learner_group: Any = None
     world_group: Any = None
-    cohort_group: Any = None          # split layout: one learner + the actors that feed it
-    cohort_ranks: list[int] = field(default_factory=list)
     owns_process_group: bool = True
-    _side_stream: Any = field(default=None, repr=False)
-    _pending_weight_work: Any = field(default=None, repr=False)
-    _staging: torch.Tensor | None = field(default=None, repr=False)
+    control_group: Any = None         # gloo side group for host-side agreement (None: the world group is gloo already)
+    learner_control_group: Any = None  # the same for the learner ranks only (split layout with several learners)
+    control: ControlPlane | None = None
+    pair_groups: dict[tuple[int, int], tuple[Any, Any]] = field(default_factory=dict)  # (learner, actor) -> (experience, weight) groups
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -110,38 +156,6 @@ class DistContext:
         src_rank = self.layout.learner_ranks[0] if src is None else src
         self._collective(dist.broadcast, flat_param, src=src_rank, group=self.world_group)
 
-    def broadcast_weights_async(self, flat_param: torch.Tensor) -> None:
-        """Start a broadcast into a staging buffer on a side stream; ``finish_weight_broadcast`` swaps it in.
-
-        The side stream uses the default priority.  Senders stage a snapshot so the learner may keep
-        updating ``flat_param`` while the wire transfer is in flight.
-        """
-        src_rank = self.layout.learner_ranks[0]
-        if self._host_staged() or not flat_param.is_cuda:
-            self.broadcast_weights(flat_param, src_rank)
-            return
-        if self._staging is None or self._staging.numel() != flat_param.numel():
-            self._staging = torch.empty_like(flat_param)
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-        self._side_stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self._side_stream):
-            if self.rank == src_rank:
-                self._staging.copy_(flat_param, non_blocking=True)
-            self._pending_weight_work = dist.broadcast(self._staging, src=src_rank, group=self.world_group, async_op=True)
-
-    def finish_weight_broadcast(self, flat_param: torch.Tensor) -> bool:
-        """Complete a pending async broadcast and copy the staged weights in (non-source ranks)."""
-        if self._pending_weight_work is None:
-            return False
-        self._pending_weight_work.wait()
-        self._pending_weight_work = None
-        torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
-        if self.rank != self.layout.learner_ranks[0]:
-            assert self._staging is not None
-            flat_param.copy_(self._staging, non_blocking=True)
-        return True
-
     def all_gather_records(self, block: torch.Tensor) -> torch.Tensor:
         """All-gather equally sized record blocks ``[n, stride]``; returns ``[world, n, stride]``."""
         out_shape = (self.world_size, *block.shape)
@@ -154,24 +168,57 @@ class DistContext:
         dist.all_gather_into_tensor(out.view(-1), block.contiguous().view(-1), group=self.world_group)
         return out
 
-    def gather_blocks_to_learner(self, block: torch.Tensor) -> list[torch.Tensor] | None:
-        """Split layout: gather equally sized blocks from this rank's cohort onto its learner.
+    def agree(self, values: list[float], op: str = "min", group: str = "world") -> list[float]:
+        """Host-side all-reduce of a few numbers over every rank, or over the learner ranks (control plane, CPU tensors only).
 
-        Returns the per-cohort-member list (cohort order, the learner's own block first) on the
-        learner and ``None`` on actors.  Point-to-point under the hood: only the learner receives,
-        so actor GPUs spend no xGMI bandwidth on each other's experiences.
+        Raises :class:`PeerLostError` when a rank does not answer within the control time-out.
         """
-        if self.layout.colocated or self.cohort_group is None:
-            raise RuntimeError("gather_blocks_to_learner needs the split role layout")
-        dst = self.cohort_ranks[0]
-        staged = self._host_staged() and block.is_cuda
-        send = block.detach().to("cpu", non_blocking=False).contiguous() if staged else block.contiguous()
-        if self.rank == dst:
-            outs = [torch.empty_like(send) for _ in self.cohort_ranks]
-            dist.gather(send, gather_list=outs, dst=dst, group=self.cohort_group)
-            return [o.to(block.device, non_blocking=False) for o in outs] if staged else outs
-        dist.gather(send, gather_list=None, dst=dst, group=self.cohort_group)
-        return None
+        members = self.world_size if group == "world" else self.num_learners
+        if members <= 1:
+            return [float(v) for v in values]
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        rop = {"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op]
+        if group == "world":
+            grp, side = (self.control_group, True) if self.control_group is not None else (self.world_group, False)
+        else:
+            grp, side = (self.learner_control_group, True) if self.learner_control_group is not None else (self.learner_group, False)
+        if not side and not self._host_staged():
+            t = t.to(self.device)  # no side group was created: fall back to the data plane
+        try:
+            dist.all_reduce(t, op=rop, group=grp)
+        except RuntimeError as exc:
+            raise PeerLostError(f"rank {self.rank}: control-plane agreement failed ({exc})") from exc
+        return [float(x) for x in t.cpu().tolist()]
+
+    # ------------------------------------------------------------------ point to point (split layout)
+    def _pair(self, learner: int, actor: int, weights: bool) -> Any:
+        try:
+            return self.pair_groups[(learner, actor)][1 if weights else 0]
+        except KeyError:
+            raise RuntimeError(f"no point-to-point group for learner {learner} / actor {actor}") from None
+
+    def send_to(self, tensor: torch.Tensor, peer: int, *, learner: int, actor: int, weights: bool) -> None:
+        """Blocking-on-stream send of ``tensor`` to ``peer`` on the pair's experience or weight communicator."""
+        grp = self._pair(learner, actor, weights)
+        if self._host_staged() and tensor.is_cuda:
+            tensor = tensor.detach().to("cpu", non_blocking=False)
+        try:
+            dist.send(tensor.contiguous(), dst=peer, group=grp)
+        except RuntimeError as exc:
+            raise PeerLostError(f"rank {self.rank}: send to rank {peer} failed ({exc})") from exc
+
+    def recv_from(self, tensor: torch.Tensor, peer: int, *, learner: int, actor: int, weights: bool) -> None:
+        """Receive into ``tensor`` (contiguous) from ``peer`` on the pair's experience or weight communicator."""
+        grp = self._pair(learner, actor, weights)
+        try:
+            if self._host_staged() and tensor.is_cuda:
+                host = torch.empty(tensor.shape, dtype=tensor.dtype)
+                dist.recv(host, src=peer, group=grp)
+                tensor.copy_(host, non_blocking=False)
+            else:
+                dist.recv(tensor, src=peer, group=grp)
+        except RuntimeError as exc:
+            raise PeerLostError(f"rank {self.rank}: receive from rank {peer} failed ({exc})") from exc
 
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
         """In-place MAX all-reduce of a small control tensor over every rank."""
@@ -186,7 +233,7 @@ class DistContext:
         return float(t.item())
 
     def warm_up(self) -> None:
-        """One tiny all-reduce on every group this rank belongs to (world, learners, cohort), in that order.
+        """One tiny transfer on every communicator this rank belongs to (world, learners, its point-to-point pairs).
 
         RCCL builds a communicator's channels (device allocations, IPC handles) on its first collective; doing that
         here keeps it out of the HIP-graph captures of the first self-play move and the first learner step, during
@@ -195,12 +242,20 @@ class DistContext:
         for grp, member in (
             (self.world_group, True),
             (self.learner_group, self.learner_group is not None and self.is_learner),
-            (self.cohort_group, self.cohort_group is not None),
         ):
             if not member or (grp is None and grp is not self.world_group):
                 continue
             t = torch.zeros(1, dtype=torch.float32, device="cpu" if self._host_staged() else self.device)
             dist.all_reduce(t, group=grp)
+        # point-to-point communicators of the split layout: one tiny transfer per pair and direction, in a fixed order
+        for (learner, actor), _groups in sorted(self.pair_groups.items()):
+            t = torch.zeros(1, dtype=torch.float32, device="cpu" if self._host_staged() else self.device)
+            if self.rank == actor:
+                self.send_to(t, learner, learner=learner, actor=actor, weights=False)
+                self.recv_from(t, learner, learner=learner, actor=actor, weights=True)
+            else:
+                self.recv_from(t, actor, learner=learner, actor=actor, weights=False)
+                self.send_to(t, actor, learner=learner, actor=actor, weights=True)
         if not self._host_staged():
             torch.cuda.synchronize(self.device)
 
@@ -232,9 +287,14 @@ def init_distributed(
     layout: str = "colocated",
     num_learners: int = 1,
     init_method: str | None = None,
-    timeout_s: float = 600.0,
+    timeout_s: float = 120.0,
+    control_timeout_s: float = 60.0,
 ) -> DistContext:
-    """Create the process group (if needed) and the role sub-groups.  Every rank must call this."""
+    """Create the process group (if needed) and the role sub-groups.  Every rank must call this.
+
+    ``timeout_s`` bounds every data-plane collective (a missing rank ends the others non-zero after it);
+    ``control_timeout_s`` bounds the host-side agreements, which is where a lost rank is noticed first.
+    """
     be = _pick_backend(backend)
     if be == "nccl":
         n_dev = torch.cuda.device_count()
@@ -259,14 +319,31 @@ def init_distributed(
     roles = RoleLayout.build(world_size, layout, num_learners)
     # new_group must be called by every rank, in the same order
     learner_group = dist.new_group(ranks=roles.learner_ranks) if len(roles.learner_ranks) < world_size else None
-    cohort_group, cohort_ranks = None, []
+    # control plane: a gloo side group when the data plane is RCCL (host tensors, short time-out)
+    control_group = None
+    if be == "nccl" and world_size > 1:
+        control_group = dist.new_group(ranks=list(range(world_size)), backend="gloo",
+                                       timeout=datetime.timedelta(seconds=control_timeout_s))
+    learner_control_group = None
+    if be == "nccl" and 1 < len(roles.learner_ranks) < world_size:
+        learner_control_group = dist.new_group(ranks=roles.learner_ranks, backend="gloo",
+                                               timeout=datetime.timedelta(seconds=control_timeout_s))
+    # split layout: two 2-rank groups per (learner, actor) pair, one per direction of traffic, so that an experience
+    # shipment and a weight delivery between the same two ranks never queue behind each other on one communicator
+    pair_groups: dict[tuple[int, int], tuple[Any, Any]] = {}
     if not roles.colocated:
         n_l = len(roles.learner_ranks)
-        for li, lr in enumerate(roles.learner_ranks):
-            members = [lr] + [a for ai, a in enumerate(roles.actor_ranks) if ai % n_l == li]
-            grp = dist.new_group(ranks=members)  # every rank creates every cohort group, in the same order
-            if rank in members:
-                cohort_group, cohort_ranks = grp, members
+        for ai, a in enumerate(roles.actor_ranks):
+            lr = roles.learner_ranks[ai % n_l]
+            g_exp = dist.new_group(ranks=[lr, a])
+            g_w = dist.new_group(ranks=[lr, a])
+            if rank in (lr, a):
+                pair_groups[(lr, a)] = (g_exp, g_w)
+    control = None
+    try:
+        control = ControlPlane(dist.distributed_c10d._get_default_store())
+    except Exception:  # pragma: no cover - a process group created elsewhere without a default store
+        logger.debug("no default store available for the control plane", exc_info=True)
     ctx = DistContext(
         rank=rank,
         world_size=world_size,
@@ -276,9 +353,11 @@ def init_distributed(
         layout=roles,
         learner_group=learner_group,
         world_group=None,
-        cohort_group=cohort_group,
-        cohort_ranks=cohort_ranks,
         owns_process_group=owns,
+        control_group=control_group,
+        learner_control_group=learner_control_group,
+        control=control,
+        pair_groups=pair_groups,
     )
     logger.info(
         "rank %d/%d backend=%s device=%s role=%s", rank, world_size, be, device, "learner+actor" if roles.colocated else ("learner" if ctx.is_learner else "actor")
@@ -299,4 +378,7 @@ def init_from_env(system_config: Any = None) -> DistContext | None:
     backend = getattr(system_config, "DIST_BACKEND", "auto") if system_config is not None else "auto"
     layout = getattr(system_config, "ROLE_LAYOUT", "colocated") if system_config is not None else "colocated"
     n_learn = getattr(system_config, "NUM_LEARNER_RANKS", 1) if system_config is not None else 1
-    return init_distributed(rank, world, local_rank, backend, layout, n_learn, init_method="env://")
+    timeout_s = float(getattr(system_config, "COLLECTIVE_TIMEOUT_S", 120.0)) if system_config is not None else 120.0
+    control_s = float(getattr(system_config, "CONTROL_TIMEOUT_S", 60.0)) if system_config is not None else 60.0
+    return init_distributed(rank, world, local_rank, backend, layout, n_learn, init_method="env://",
+                            timeout_s=timeout_s, control_timeout_s=control_s)

@@ -6,11 +6,22 @@ one ``play_move`` call advances every game by one move - root evaluation, Dirich
 noise, ``max_simulations`` simulation waves (tree kernel -> network forward over all
 leaves), policy target + action sampling, n-step bookkeeping, experience emission into
 the HBM replay, re-rooting with subtree reuse.  The steady-state wave
-(tree kernel + ~25 network kernels) is captured once into a HIP graph and replayed.
+(tree kernel + the network kernels) is captured once into a HIP graph and replayed.
+
+Leaf evaluation is pluggable (:class:`LeafEvaluator`): the hand-written HIP engine in
+bf16 or in its fp32-grade split-precision mode, or - for model configurations the
+kernels do not tile - the PyTorch module itself in fp32, driving the same tree kernels
+(alphatriangle/nn/network.py:243-318 is the reference's leaf-evaluation entry point).
+
+Every evaluation is checked on the device (the reference raises on non-finite outputs:
+alphatriangle/nn/network.py:177-191,260-274): the tree kernel counts leaves whose logits
+or value were not finite, gives them a uniform prior so the search stays well defined,
+and ``finish_move`` raises :class:`NetworkEvaluationError` when the count is not zero.
 """
 
 from __future__ import annotations
 
+import copy
 import logging
 import time
 from dataclasses import dataclass, field
@@ -24,8 +35,8 @@ from ...config.mcts_config import AlphaTriangleMCTSConfig
 from ...config.model_config import ModelConfig
 from ...config.system_config import SystemConfig
 from ...config.train_config import TrainConfig
-from ...models.network import NeuralNetwork
-from ...ops.engine import GpuTreeEngine
+from ...models.network import NetworkEvaluationError, NeuralNetwork
+from ...ops.engine import CENSUS_NON_FINITE, SLOT_DEPTHCAP, SLOT_EXPAND, SLOT_NONE, SLOT_TERMINAL, GpuTreeEngine
 from ...rl.core.device_buffer import DeviceReplayBuffer
 
 logger = logging.getLogger(__name__)
@@ -44,6 +55,108 @@ class GpuMoveReport:
     triangles_cleared: int = 0
     trainer_step: int = 0
     seconds: float = 0.0
+    # one entry per game that moved: the per-game-step metrics of the reference's worker
+    # (alphatriangle/rl/self_play/worker.py:398-408,443-447)
+    per_game: dict[str, np.ndarray] = field(default_factory=dict)
+    # leaf slots of this move by kind; ``expand`` slots are the ones that needed a network evaluation
+    slot_census: dict[str, int] = field(default_factory=dict)
+
+
+class LeafEvaluator:
+    """Evaluates the network on the tree's leaf rows; results land in ``logits`` / ``values`` (stable addresses)."""
+
+    logits: torch.Tensor
+    values: torch.Tensor
+    graph_safe = False
+    dtype = "fp32"
+
+    def forward(self, grid: torch.Tensor, other: torch.Tensor) -> None:
+        raise NotImplementedError
+
+    def refresh(self) -> None:
+        """Pick up the learner's current parameters."""
+        raise NotImplementedError
+
+
+class EngineEvaluator(LeafEvaluator):
+    """The hand-written HIP network (ops/inference.py)."""
+
+    graph_safe = True
+
+    def __init__(self, nn: NeuralNetwork, batch: int):
+        self.nn = nn
+        self.engine = nn.engine
+        self.engine.reserve(batch)
+        self.logits = self.engine.logits
+        self.values = self.engine.values
+        self.dtype = getattr(self.engine, "dtype", "bf16")
+
+    def forward(self, grid: torch.Tensor, other: torch.Tensor) -> None:
+        self.engine.forward(grid, other)
+
+    def refresh(self) -> None:
+        self.nn.sync_inference_weights()
+
+
+class ModuleEvaluator(LeafEvaluator):
+    """The PyTorch module in eval mode and fp32: any ``ModelConfig`` the reference accepts, same tree kernels.
+
+    It keeps a private eval-mode copy of the module, because the learner switches the shared one to training mode
+    (BatchNorm batch statistics, dropout) and may update it on another stream while a search is running.
+    """
+
+    def __init__(self, nn: NeuralNetwork, batch: int, chunk: int = 2048):
+        self.nn = nn
+        dev = nn.device
+        mc, ec = nn.model_config, nn.env_config
+        self.module = copy.deepcopy(nn._orig_model).to(dev).eval()
+        for p in self.module.parameters():
+            p.requires_grad_(False)
+        self.A = nn.action_dim
+        stride = (self.A + 7) // 8 * 8
+        self.logits = torch.zeros(batch, stride, dtype=torch.float32, device=dev)
+        self.values = torch.zeros(batch, dtype=torch.float32, device=dev)
+        self.support = nn.support.float()
+        self.shape = (mc.GRID_INPUT_CHANNELS, ec.ROWS, ec.COLS)
+        self.cells = ec.ROWS * ec.COLS
+        # channel 0 carries the board; further input channels stay zero (alphatriangle/features/extractor.py:33-46)
+        self.planes = torch.zeros(batch, *self.shape, dtype=torch.float32, device=dev) if self.shape[0] > 1 else None
+        self.chunk = int(chunk)
+
+    @torch.no_grad()
+    def forward(self, grid: torch.Tensor, other: torch.Tensor) -> None:
+        B = int(grid.shape[0])
+        if self.planes is not None:
+            self.planes[:B, 0] = grid.view(B, self.shape[1], self.shape[2])
+            x = self.planes[:B]
+        else:
+            x = grid.view(B, *self.shape)
+        for s in range(0, B, self.chunk):
+            e = min(B, s + self.chunk)
+            pl, vl = self.module(x[s:e], other[s:e])
+            self.logits[s:e, : self.A].copy_(pl.float())
+            torch.sum(torch.softmax(vl.float(), dim=1) * self.support, dim=1, out=self.values[s:e])
+
+    @torch.no_grad()
+    def refresh(self) -> None:
+        src = self.nn._orig_model.state_dict()
+        for k, v in self.module.state_dict().items():
+            v.copy_(src[k])
+
+
+def make_evaluator(nn: NeuralNetwork, system_config: SystemConfig, batch: int) -> LeafEvaluator:
+    """The fastest evaluator that honours ``SystemConfig.INFERENCE_DTYPE`` for this model configuration."""
+    want = str(getattr(system_config, "INFERENCE_DTYPE", "bf16"))
+    engine = nn.engine
+    if engine is not None and getattr(engine, "dtype", "bf16") == want:
+        return EngineEvaluator(nn, batch)
+    if engine is not None and want == "bf16":
+        return EngineEvaluator(nn, batch)
+    if engine is None:
+        logger.warning("No HIP inference engine for this model configuration: leaves are evaluated by the PyTorch module (fp32).")
+    else:
+        logger.info("INFERENCE_DTYPE=%s: leaves are evaluated by the PyTorch module in fp32.", want)
+    return ModuleEvaluator(nn, batch)
 
 
 class GpuSelfPlayActor:
@@ -58,11 +171,8 @@ class GpuSelfPlayActor:
         replay: DeviceReplayBuffer,
         device: torch.device,
         seed: int = 0,
+        evaluator: LeafEvaluator | None = None,
     ):
-        if nn.engine is None:
-            raise RuntimeError(
-                "GpuSelfPlayActor needs the HIP inference engine (unsupported model config or missing libatri_hip.so)"
-            )
         self.env_config = env_config
         self.mcts_config = mcts_config
         self.train_config = train_config
@@ -73,11 +183,10 @@ class GpuSelfPlayActor:
         self.G = int(system_config.GAMES_PER_GPU)
         self.L = int(system_config.LEAVES_PER_TREE)
         self.B = self.G * self.L
-        self.engine = nn.engine
-        self.engine.reserve(self.B)
+        self.evaluator = evaluator if evaluator is not None else make_evaluator(nn, system_config, self.B)
         self.tree = GpuTreeEngine(
             env_config, mcts_config, self.device, self.G, self.L, model_config.OTHER_NN_INPUT_FEATURES_DIM,
-            self.engine.logits, self.engine.values, seed=seed,
+            self.evaluator.logits, self.evaluator.values, seed=seed,
         )
         if system_config.TEMPERATURE_SWITCH_GAME_STEP is not None:
             switch = int(system_config.TEMPERATURE_SWITCH_GAME_STEP)
@@ -101,23 +210,30 @@ class GpuSelfPlayActor:
         self._graph: torch.cuda.CUDAGraph | None = None
         self._t0 = time.perf_counter()
         self.profile_ranges = bool(train_config.PROFILE_WORKERS)  # --profile: roctx ranges around the move phases
-        self._use_graph = bool(system_config.USE_HIP_GRAPHS)
+        self._use_graph = bool(system_config.USE_HIP_GRAPHS) and self.evaluator.graph_safe
+        self.per_game_metrics = True
         self._grid_view = self.tree.nn_grid
         self._other_view = self.tree.nn_other
         logger.info(
-            "GPU self-play actor: %d games, %d leaves/tree, %d sims/move -> network batch %d, %d waves/move",
-            self.G, self.L, mcts_config.max_simulations, self.B, self.waves_per_move,
+            "GPU self-play actor: %d games, %d leaves/tree, %d sims/move -> network batch %d, %d waves/move, evaluator %s (%s)",
+            self.G, self.L, mcts_config.max_simulations, self.B, self.waves_per_move, type(self.evaluator).__name__,
+            self.evaluator.dtype,
         )
+
+    @property
+    def dtype(self) -> str:
+        """Precision of the leaf evaluations that drive the search."""
+        return self.evaluator.dtype
 
     # ------------------------------------------------------------------ weights
     def sync_weights(self, trainer_step: int) -> None:
-        """Re-fold + re-pack the learner's current parameters into the inference engine (in place)."""
-        self.nn.sync_inference_weights()
+        """Make the evaluator use the learner's current parameters (re-fold + re-pack in place for the HIP engine)."""
+        self.evaluator.refresh()
         self.current_trainer_step = int(trainer_step)
 
     # ------------------------------------------------------------------ one simulation wave
     def _forward(self) -> None:
-        self.engine.forward(self._grid_view, self._other_view)
+        self.evaluator.forward(self._grid_view, self._other_view)
 
     def _steady_wave(self) -> None:
         self.tree.wave(consume=True, select=True)
@@ -144,6 +260,7 @@ class GpuSelfPlayActor:
         self._t0 = time.perf_counter()
         tree = self.tree
         tree.move_stats.zero_()
+        tree.census.zero_()
         rng = self._range
         rng("selfplay/root_eval")
         tree.prepare_roots()
@@ -182,7 +299,8 @@ class GpuSelfPlayActor:
         """Commit the move (policy targets, sampling, n-step, emission into the replay), re-root, read the counters.
 
         ``wait_event``: an event of another stream (a concurrently running learner) that must have completed
-        before the replay's sum tree is touched.
+        before the replay's sum tree is touched.  Raises :class:`NetworkEvaluationError` when any leaf evaluation
+        of this move was not finite; the move is committed first, so every kernel has run to its normal end.
         """
         t0 = self._t0
         tree = self.tree
@@ -195,6 +313,7 @@ class GpuSelfPlayActor:
         added = self.replay.end_commit()
         self._range(None)
         stats = tree.move_stats.cpu().numpy()
+        census = tree.census_totals().cpu().numpy()
         ep_total = int(tree.ep_count.item())
         new_eps = ep_total - self._ep_seen
         contexts: list[dict[str, float]] = []
@@ -208,10 +327,15 @@ class GpuSelfPlayActor:
             for i in range(take):
                 contexts.append({"score": float(score[i]), "length": int(length[i]), "simulations": int(sims[i]), "triangles_cleared": int(cleared[i])})
             self._ep_seen = ep_total
+        per_game: dict[str, np.ndarray] = {}
+        if self.per_game_metrics:
+            out = tree.step_out.cpu().numpy()
+            moved = np.isfinite(out[0])
+            per_game = {"step_reward": out[0][moved], "triangles_cleared_step": out[1][moved], "current_score": out[2][moved]}
         moves = int(stats[2])
         self.total_moves += moves
         self.total_episodes += new_eps
-        return GpuMoveReport(
+        report = GpuMoveReport(
             moves=moves,
             simulations=int(stats[4]),
             experiences_added=added,
@@ -221,7 +345,17 @@ class GpuSelfPlayActor:
             triangles_cleared=int(stats[1]),
             trainer_step=self.current_trainer_step,
             seconds=time.perf_counter() - t0,
+            per_game=per_game,
+            slot_census={"none": int(census[SLOT_NONE]), "expand": int(census[SLOT_EXPAND]),
+                         "terminal": int(census[SLOT_TERMINAL]), "depth_cap": int(census[SLOT_DEPTHCAP])},
         )
+        bad = int(census[CENSUS_NON_FINITE])
+        if bad:
+            raise NetworkEvaluationError(
+                f"{bad} leaf evaluations of this move returned non-finite policy logits or values "
+                f"(trainer step {self.current_trainer_step}); the learner's parameters have most likely diverged"
+            )
+        return report
 
     def play_move(self) -> GpuMoveReport:
         self.begin_move()

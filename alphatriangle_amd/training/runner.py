@@ -57,31 +57,17 @@ def _load_and_apply_initial_state(components: TrainingComponents) -> TrainingLoo
 
 
 def _save_final_state(loop: TrainingLoop) -> None:
+    """Final checkpoint (with the replay when the persistence config says so), then wait for the writer thread."""
     actor = loop.trieye_actor
     if not actor:
         logger.warning("Cannot save final state: stats actor not available.")
         return
-    comps = loop.components
     logger.info("Saving final training state...")
+    loop.save_state(is_best=False, save_buffer=bool(loop.trieye_config.persistence.SAVE_BUFFER))
     try:
-        save_buffer = loop.trieye_config.persistence.SAVE_BUFFER
-        buffer_data = loop.serializer.prepare_buffer_data(comps.buffer) if save_buffer else None
-        actor.save_training_state(
-            nn_state_dict=comps.nn.get_weights(),
-            optimizer_state_dict=loop.serializer.prepare_optimizer_state(comps.trainer.optimizer.state_dict()) if comps.trainer is not None else {},
-            buffer_content=buffer_data.buffer_list if buffer_data else [],
-            global_step=loop.global_step,
-            episodes_played=loop.episodes_played,
-            total_simulations_run=loop.total_simulations_run,
-            is_best=False,
-            save_buffer=bool(save_buffer and buffer_data is not None),
-            model_config_dict=comps.model_config.model_dump(),
-            env_config_dict=comps.env_config.model_dump(),
-            actor_state=comps.gpu_actor.state_dict() if comps.gpu_actor is not None else None,
-        )
         actor.wait_for_saves(timeout=120.0)
     except Exception as exc:
-        logger.error("Failed to save final training state: %s", exc, exc_info=True)
+        logger.error("Waiting for the final save failed: %s", exc, exc_info=True)
 
 
 def run_training(

@@ -83,13 +83,13 @@ def setup_training_components(
         logger.info("Stats actor ready (run id %s).", stats_actor.get_mlflow_run_id())
 
         serializer = Serializer()
-        neural_net = NeuralNetwork(model_config, env_config, train_config, device)
+        neural_net = NeuralNetwork(model_config, env_config, train_config, device, inference_dtype=system_config.INFERENCE_DTYPE)
 
         use_gpu_engine = system_config.ENGINE == "gpu" or (system_config.ENGINE == "auto" and device.type == "cuda")
-        if use_gpu_engine and system_config.ENGINE == "auto" and neural_net.engine is None:
-            # a model the HIP kernels do not tile (see ops/inference.py: engine_supports): host workers + PyTorch network
-            logger.warning("SystemConfig.ENGINE='auto': no HIP inference engine for this model config; using host self-play workers.")
-            use_gpu_engine = False
+        if use_gpu_engine and neural_net.engine is None:
+            # a model the HIP kernels do not tile (see ops/inference.py: engine_supports): the GPU tree still runs,
+            # its leaves are evaluated by the PyTorch module
+            logger.warning("No HIP inference engine for this model config: GPU self-play evaluates leaves with the PyTorch module.")
         split = dist_context is not None and not dist_context.layout.colocated
         pure_actor = split and not dist_context.is_learner
         pure_learner = split and not dist_context.is_actor
@@ -153,7 +153,7 @@ def setup_training_components(
                 neural_net,
                 train_config,
                 env_config,
-                autocast_bf16=system_config.LEARNER_AUTOCAST,
+                autocast_bf16=system_config.learner_autocast(),
                 grad_sync=grad_sync,
                 world_size=n_sync,
             )

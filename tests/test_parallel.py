@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from alphatriangle_amd.config import EnvConfig, ModelConfig, TrainConfig
 from alphatriangle_amd.parallel.dist import RoleLayout, init_distributed
-from alphatriangle_amd.parallel.experience import ExperienceShipper, RecordLayout
+from alphatriangle_amd.parallel.experience import ExperienceInbox, ExperienceOutbox, RecordLayout
 
 
 def _spawn(fn, world, *args):
@@ -33,6 +33,15 @@ def _collectives(rank, world, init):
     blocks = ctx.all_gather_records(torch.full((2, 3), float(rank)))
     assert blocks.shape == (2, 2, 3) and blocks[1].eq(1).all() and blocks[0].eq(0).all()
     assert ctx.all_reduce_scalar(rank + 1.0, "max") == 2.0 and ctx.all_reduce_scalar(1.0, "sum") == 2.0
+    # control plane: host-side agreement and the key/value store
+    assert ctx.agree([float(rank), 5.0 - rank], "min") == [0.0, 4.0]
+    assert ctx.control is not None
+    ctx.control.add("hits", 1)
+    ctx.barrier()
+    assert ctx.control.counter("hits") == 2 and ctx.control.peek("absent", -7) == -7
+    ctx.control.put(f"v/{rank}", 10 + rank)
+    ctx.barrier()
+    assert ctx.control.peek(f"v/{1 - rank}") == 11 - rank
     ctx.barrier()
     ctx.shutdown()
 
@@ -102,27 +111,38 @@ def test_data_parallel_learner_equals_single_process(tmp_path):
 
 
 def _split_roles(rank, world, init):
+    import time
+
     torch.set_num_threads(1)
     ctx = init_distributed(rank, world, rank, backend="gloo", layout="split", num_learners=1, init_method=init, timeout_s=60)
     assert ctx.is_learner == (rank == 0) and ctx.is_actor == (rank != 0) and ctx.num_learners == 1
+    ctx.warm_up()  # includes one tiny transfer per point-to-point communicator
     layout = RecordLayout(grid=9, other=14, policy=9)
-    ship = ExperienceShipper(ctx, layout, capacity=8, device=torch.device("cpu"))
-    recs = None
     if ctx.is_actor:
-        n = rank + 1  # actor 1 ships 2 records, actor 2 ships 3
+        out = ExperienceOutbox(ctx, layout, torch.device("cpu"), max_rows=8)
+        n = rank + 1  # actor 1 ships 2 records, actor 2 ships 3; then an empty move
         recs = layout.pack(torch.full((n, 1, 3, 3), float(rank)), torch.zeros(n, 14), torch.full((n, 9), 1 / 9), torch.full((n,), 0.5 * rank))
-    got = ship.exchange(recs)
-    if ctx.is_learner:
-        assert got.shape == (5, layout.stride)
-        g, o, p, r = layout.unpack(got)
-        assert sorted(r.tolist()) == [0.5, 0.5, 1.0, 1.0, 1.0] and torch.allclose(p.sum(1), torch.ones(5))
+        assert out.ship(recs, {"episodes": 1, "simulations": 10 * rank, "moves": n}) == n
+        assert out.ship(None, {"episodes": 0, "simulations": 0, "moves": 1}) == 0
+        out.close()
     else:
-        assert got.shape[0] == 0
-    # learner -> actors weight push
+        inbox = ExperienceInbox(ctx, layout, torch.device("cpu"))
+        got, deadline = [], time.monotonic() + 30
+        while not inbox.drained() and time.monotonic() < deadline:
+            got += inbox.poll()
+            time.sleep(0.01)
+        assert inbox.drained() and len(got) == 4
+        rows = torch.cat([s.records for s in got])
+        assert rows.shape == (5, layout.stride)  # exactly the rows that exist: no fixed-size padding travels
+        g, o, p, r = layout.unpack(rows)
+        assert sorted(r.tolist()) == [0.5, 0.5, 1.0, 1.0, 1.0] and torch.allclose(p.sum(1), torch.ones(5))
+        assert sum(s.counters["simulations"] for s in got) == 30 and sum(s.counters["moves"] for s in got) == 7
+    # learner -> actors weight push (collective form)
     w = torch.arange(5.0) if ctx.is_learner else torch.zeros(5)
     ctx.broadcast_weights(w)
     assert torch.equal(w, torch.arange(5.0))
     ctx.grad_sync(torch.ones(3))  # single learner: no-op, must not hang
+    ctx.barrier()
     ctx.shutdown()
 
 
