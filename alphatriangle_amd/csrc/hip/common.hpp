@@ -33,6 +33,23 @@ __device__ __forceinline__ short8 pack_bf16x8(float a0, float a1, float a2, floa
   return __builtin_bit_cast(short8, u);
 }
 
+// fp32 -> (hi, lo) bf16 pair with hi + lo carrying 16 significant bits of x: hi = bf16(x), lo = bf16(x - hi).
+// Products of such pairs on the bf16 matrix cores (hi*hi + lo*hi + hi*lo, fp32 accumulation) are the fp32-grade
+// GEMM of the split_* kernels.  A NaN or an infinity stays visible: hi carries it, lo becomes NaN.
+__device__ __forceinline__ void split_bf16x8(const float (&v)[8], short8& hi, short8& lo) {
+  hi = pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = v[j] - bf16_to_float((unsigned short)hi[j]);
+  lo = pack_bf16x8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+}
+// acc += A B for operands given as (hi, lo) pairs: three MFMA passes, smallest terms first.
+__device__ __forceinline__ float4v mfma_split(const short8& ah, const short8& al, const short8& bh, const short8& bl, float4v acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

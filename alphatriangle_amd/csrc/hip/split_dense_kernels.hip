@@ -1,0 +1,362 @@
+// fp32-grade dense tail of the network: shared FC over the flattened body (split-K, final LayerNorm fused into the
+// staging), policy / value heads and the C51 expectation (alphatriangle/nn/model.py:232-266,
+// alphatriangle/nn/network.py:157-162).  Activations are fp32 in memory and in every element-wise step; each GEMM is
+// three bf16 MFMA passes over (hi, lo) operand splits (see split_conv_kernels.hip for the scheme).
+#include "common.hpp"
+
+using namespace atrihip;
+
+namespace {
+constexpr int kPitch = 272;  // bytes per 128-wide bf16 LDS row (256 + 16)
+}
+
+// Shared FC fed directly by the body's [B][HW][128] fp32 rows.  The final LayerNorm - when there is one - is
+// applied in fp32 to each 128-wide pixel row while it is staged (16 lanes per row), the row is then split into
+// the two bf16 planes; the "other" features are read from the caller's f32 rows as the last K steps.
+// steps_per_split is a multiple of 4, so every staged chunk of 4 K-steps is exactly one pixel row.
+template <int MT>
+__global__ __launch_bounds__(256, 2) void fc_rows_split_kernel(const float* __restrict__ rows, const float* __restrict__ other,
+                                                              int other_dim, const float* __restrict__ g,
+                                                              const float* __restrict__ bt, float eps,
+                                                              const unsigned short* __restrict__ Wp, long long lo_off,
+                                                              float* __restrict__ slabs, int B, int HW, int other_pad, int N,
+                                                              int steps_per_split) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs[2][MT * 16 * kPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b0 = blockIdx.x * (MT * 16);
+  const int feat_steps = HW * 4;
+  const int total_steps = feat_steps + (other_pad >> 5);
+  const int s_begin = blockIdx.y * steps_per_split;
+  const int s_end = min(s_begin + steps_per_split, total_steps);
+  float4v acc[MT][2];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
+    acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool wave_active = wave * 32 < N;
+  const short8* wph = reinterpret_cast<const short8*>(Wp) + (size_t)wave * 128 + lane;
+  const short8* wpl = reinterpret_cast<const short8*>(Wp + lo_off) + (size_t)wave * 128 + lane;
+  float gg[8], bb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    gg[j] = g != nullptr ? g[(tid & 15) * 8 + j] : 1.f;
+    bb[j] = g != nullptr ? bt[(tid & 15) * 8 + j] : 0.f;
+  }
+  auto load_rows = [&](int s0, float4 (&v)[MT][2]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int c = tid + i * 256, r = c >> 4, cc = c & 15;
+      v[i][0] = v[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s0 < s_end && b0 + r < B) {
+        if (s0 < feat_steps) {
+          const float4* p = reinterpret_cast<const float4*>(rows + ((size_t)(b0 + r) * HW + (s0 >> 2)) * 128 + cc * 8);
+          v[i][0] = p[0];
+          v[i][1] = p[1];
+        } else {  // the "other" features (zero padded to other_pad)
+          const int d0 = (s0 - feat_steps) * 32 + cc * 8;
+          float f[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = d0 + j < other_dim ? other[(size_t)(b0 + r) * other_dim + d0 + j] : 0.f;
+          v[i][0] = make_float4(f[0], f[1], f[2], f[3]);
+          v[i][1] = make_float4(f[4], f[5], f[6], f[7]);
+        }
+      }
+    }
+  };
+  float4 v[MT][2];
+  load_rows(s_begin, v);
+  for (int s0 = s_begin; s0 < s_end; s0 += 4) {
+    short8 wh[4][2], wl[4][2];
+    if (wave_active) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int step = min(s0 + ks, s_end - 1);  // steps beyond the split are loaded but not multiplied
+        wh[ks][0] = wph[(size_t)step * 512];
+        wh[ks][1] = wph[(size_t)step * 512 + 64];
+        wl[ks][0] = wpl[(size_t)step * 512];
+        wl[ks][1] = wpl[(size_t)step * 512 + 64];
+      }
+    }
+    __syncthreads();  // the previous iteration's MFMAs are done reading the tile
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int c = tid + i * 256, r = c >> 4, cc = c & 15;
+      float f[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
+      if (g != nullptr && s0 < feat_steps) {  // block-uniform branch: all 16 lanes of a row take it together
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += f[j];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s * (1.0f / 128.0f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f[j] -= mean;
+          ss += f[j] * f[j];
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = f[j] * rstd * gg[j] + bb[j];
+      }
+      short8 xh, xl;
+      split_bf16x8(f, xh, xl);
+      *reinterpret_cast<short8*>(xs[0] + r * kPitch + cc * 16) = xh;
+      *reinterpret_cast<short8*>(xs[1] + r * kPitch + cc * 16) = xl;
+    }
+    __syncthreads();
+    load_rows(s0 + 4, v);  // next pixel row: in flight during the MFMAs below
+    if (!wave_active) continue;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (s0 + ks >= s_end) break;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const short8 xh = *reinterpret_cast<const short8*>(xs[0] + (t * 16 + l15) * kPitch + ks * 64 + q4 * 16);
+        const short8 xl = *reinterpret_cast<const short8*>(xs[1] + (t * 16 + l15) * kPitch + ks * 64 + q4 * 16);
+        acc[t][0] = mfma_split(wh[ks][0], wl[ks][0], xh, xl, acc[t][0]);
+        acc[t][1] = mfma_split(wh[ks][1], wl[ks][1], xh, xl, acc[t][1]);
+      }
+    }
+  }
+  if (!wave_active) return;
+  float* slab = slabs + (size_t)blockIdx.y * B * 128;
+  const int ch0 = wave * 32 + q4 * 8;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int bi = b0 + t * 16 + l15;
+    if (bi >= B) continue;
+    float* op = slab + (size_t)bi * 128 + ch0;
+    *reinterpret_cast<float4*>(op) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
+    *reinterpret_cast<float4*>(op + 4) = make_float4(acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct SplitHeadsArgs {
+  const float* slabs;          // [SK][B][128] split-K partial sums of the shared FC layer
+  const float* fc_bias;        // [128]
+  const unsigned short* wp1;   // packed [hi | lo] fragments: policy hidden 128 -> 128
+  const float* bp1;
+  const unsigned short* wp2;   // policy logits 128 -> A
+  const float* bp2;
+  const unsigned short* wv1;   // value hidden 128 -> 128
+  const float* bv1;
+  const unsigned short* wv2;   // value logits 128 -> atoms (one block)
+  const float* bv2;
+  long long lo_p1, lo_p2, lo_v1, lo_v2;
+  float* logits;               // [B][logit_stride]
+  float* vlogits;              // [B][value_stride]
+  float* values;               // [B]
+  int B, SK, act, nbp, a_store, logit_stride, atoms, atoms_store, value_stride;
+  float vmin, dz;
+};
+
+namespace {
+constexpr int kHeadRowsS = 16;
+constexpr int kHeadPitchS = 288;
+
+__device__ __forceinline__ float4v act4h(float4v v, int act) {
+  if (act == kActReLU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+  } else if (act != kActNone) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], act);
+  }
+  return v;
+}
+
+// acc[n] += W x for the 128-deep layer whose packed (hi | lo) fragments start at w; tile_h / tile_l are this lane's rows
+__device__ __forceinline__ void gemm128_split(const unsigned short* __restrict__ w, long long lo_off, size_t frag_index,
+                                              const unsigned char* __restrict__ tile_h, const unsigned char* __restrict__ tile_l,
+                                              float4v (&acc)[2]) {
+  const short8* wph = reinterpret_cast<const short8*>(w) + frag_index;
+  const short8* wpl = reinterpret_cast<const short8*>(w + lo_off) + frag_index;
+  short8 wh[4][2], wl[4][2];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    wh[kc][0] = wph[kc * 512];
+    wh[kc][1] = wph[kc * 512 + 64];
+    wl[kc][0] = wpl[kc * 512];
+    wl[kc][1] = wpl[kc * 512 + 64];
+  }
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    const short8 xh = *reinterpret_cast<const short8*>(tile_h + kc * 64);
+    const short8 xl = *reinterpret_cast<const short8*>(tile_l + kc * 64);
+    acc[0] = mfma_split(wh[kc][0], wl[kc][0], xh, xl, acc[0]);
+    acc[1] = mfma_split(wh[kc][1], wl[kc][1], xh, xl, acc[1]);
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_tile[2][kHeadRowsS * kHeadPitchS];
+  __shared__ __attribute__((aligned(16))) unsigned char p_tile[2][kHeadRowsS * kHeadPitchS];
+  __shared__ __attribute__((aligned(16))) unsigned char v_tile[2][kHeadRowsS * kHeadPitchS];
+  __shared__ float vl[kHeadRowsS][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b0 = blockIdx.x * kHeadRowsS;
+
+  // ---- shared FC: sum the split-K slabs, bias, activation (fp32) -> s_tile planes (thread = sample, 8 channels) ----
+  {
+    const int r = tid >> 4, n0 = (tid & 15) * 8;
+    const int b = b0 + r;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (b < a.B) {
+      const float4* bp = reinterpret_cast<const float4*>(a.fc_bias + n0);
+      const float4 c0 = bp[0], c1 = bp[1];
+      v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
+      v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+      for (int s = 0; s < a.SK; ++s) {
+        const float4* sp = reinterpret_cast<const float4*>(a.slabs + ((size_t)s * a.B + b) * 128 + n0);
+        const float4 p0 = sp[0], p1 = sp[1];
+        v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
+        v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+      }
+      const float4v lo = act4h((float4v){v[0], v[1], v[2], v[3]}, a.act);
+      const float4v hi = act4h((float4v){v[4], v[5], v[6], v[7]}, a.act);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = lo[j];
+        v[4 + j] = hi[j];
+      }
+    }
+    short8 xh, xl;
+    split_bf16x8(v, xh, xl);
+    *reinterpret_cast<short8*>(s_tile[0] + r * kHeadPitchS + n0 * 2) = xh;
+    *reinterpret_cast<short8*>(s_tile[1] + r * kHeadPitchS + n0 * 2) = xl;
+  }
+  __syncthreads();
+
+  // ---- hidden layers of both heads: wave = 32 output channels, lane ends with 8 consecutive channels of sample l15 ----
+  const int lane_off = l15 * kHeadPitchS + q4 * 16;
+  const int ch = wave * 32 + q4 * 8;
+  const size_t frag = (size_t)wave * 128 + lane;
+#pragma unroll
+  for (int head = 0; head < 2; ++head) {
+    float4v acc[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
+    gemm128_split(head == 0 ? a.wp1 : a.wv1, head == 0 ? a.lo_p1 : a.lo_v1, frag, s_tile[0] + lane_off, s_tile[1] + lane_off, acc);
+    const float* bias = (head == 0 ? a.bp1 : a.bv1) + ch;
+    float4v lo = acc[0], hi = acc[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lo[j] += bias[j];
+      hi[j] += bias[4 + j];
+    }
+    lo = act4h(lo, a.act);
+    hi = act4h(hi, a.act);
+    const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    short8 xh, xl;
+    split_bf16x8(f, xh, xl);
+    unsigned char* dh = (head == 0 ? p_tile[0] : v_tile[0]) + l15 * kHeadPitchS + ch * 2;
+    unsigned char* dl = (head == 0 ? p_tile[1] : v_tile[1]) + l15 * kHeadPitchS + ch * 2;
+    *reinterpret_cast<short8*>(dh) = xh;
+    *reinterpret_cast<short8*>(dl) = xl;
+  }
+  __syncthreads();
+
+  // ---- value logits (one 128-channel block; waves beyond the atom count idle) -> LDS + memory ----
+  const int b = b0 + l15;
+  if (wave * 32 < a.atoms_store) {
+    float4v acc[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
+    gemm128_split(a.wv2, a.lo_v2, frag, v_tile[0] + lane_off, v_tile[1] + lane_off, acc);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = ch + n * 4 + j;
+        const float v = acc[n][j] + a.bv2[c];
+        vl[l15][c] = v;
+        if (b < a.B && c < a.atoms_store) a.vlogits[(size_t)b * a.value_stride + c] = v;
+      }
+    }
+  }
+  // ---- policy logits: NBP blocks of 128 channels ----
+  for (int nb = 0; nb < a.nbp; ++nb) {
+    if (nb * 128 + wave * 32 >= a.a_store) break;  // wave-uniform
+    float4v acc[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
+    gemm128_split(a.wp2, a.lo_p2, ((size_t)nb * 16 + wave) * 128 + lane, p_tile[0] + lane_off, p_tile[1] + lane_off, acc);
+    const int c0 = nb * 128 + ch;
+    if (b < a.B && c0 < a.a_store) {
+      const float4* bp = reinterpret_cast<const float4*>(a.bp2 + c0);
+      const float4 bl = bp[0], bh = bp[1];
+      float4* out = reinterpret_cast<float4*>(a.logits + (size_t)b * a.logit_stride + c0);
+      out[0] = make_float4(acc[0][0] + bl.x, acc[0][1] + bl.y, acc[0][2] + bl.z, acc[0][3] + bl.w);
+      out[1] = make_float4(acc[1][0] + bh.x, acc[1][1] + bh.y, acc[1][2] + bh.z, acc[1][3] + bh.w);
+    }
+  }
+  __syncthreads();
+
+  // ---- C51 expectation: 16 lanes per sample, atoms strided over them ----
+  {
+    const int r = tid >> 4, l = tid & 15;
+    float m = -1e30f;
+    for (int i = l; i < a.atoms; i += 16) m = fmaxf(m, vl[r][i]);
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float s = 0.f, e = 0.f;
+    for (int i = l; i < a.atoms; i += 16) {
+      const float p = expf(vl[r][i] - m);
+      s += p;
+      e += p * (a.vmin + (float)i * a.dz);
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      s += __shfl_xor(s, off, 64);
+      e += __shfl_xor(e, off, 64);
+    }
+    if (l == 0 && b0 + r < a.B) a.values[b0 + r] = e / s;
+  }
+}
+
+extern "C" {
+
+int atri_split_fc_rows(const float* rows, const float* other, int other_dim, const float* g, const float* bt, float eps,
+                       const void* Wp, long long lo_off, float* slabs, int B, int HW, int D, int other_pad, int N, int SK,
+                       int steps_per_split, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (D != 128 || (other_pad & 31) != 0 || other_dim < 0 || other_dim > other_pad || N > 128 || (N & 31) != 0) return -10;
+  if ((steps_per_split & 3) != 0 || steps_per_split <= 0) return -11;
+  if ((long long)SK * steps_per_split < (long long)HW * 4 + (other_pad >> 5)) return -12;
+  // 64 samples per workgroup: with three MFMA passes per product the loop is matrix-core bound, and the 128-sample
+  // variant of the bf16 kernel (half the weight reads from L2) does not fit the register file next to the lo fragments
+  hipLaunchKernelGGL(fc_rows_split_kernel<4>, dim3((B + 63) / 64, SK), dim3(256), 0, stream, rows, other, other_dim, g, bt, eps,
+                       (const unsigned short*)Wp, lo_off, slabs, B, HW, other_pad, N, steps_per_split);
+  return hip_err(hipGetLastError());
+}
+
+int atri_split_heads(const float* slabs, int SK, const float* fc_bias, const void* wp1, long long lo_p1, const float* bp1,
+                     const void* wp2, long long lo_p2, const float* bp2, int nbp, int a_store, const void* wv1, long long lo_v1,
+                     const float* bv1, const void* wv2, long long lo_v2, const float* bv2, int atoms, int atoms_store,
+                     float* logits, int logit_stride, float* vlogits, int value_stride, float* values, float vmin, float dz,
+                     int B, int act, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (SK < 1 || nbp < 1 || a_store < 8 || (a_store & 7) || a_store > nbp * 128 || a_store > logit_stride) return -20;
+  if (atoms < 1 || atoms > atoms_store || atoms_store > 128 || (atoms_store & 7) || atoms_store > value_stride) return -21;
+  if (logit_stride & 3) return -22;
+  SplitHeadsArgs a{};
+  a.slabs = slabs;
+  a.fc_bias = fc_bias;
+  a.wp1 = (const unsigned short*)wp1; a.lo_p1 = lo_p1; a.bp1 = bp1;
+  a.wp2 = (const unsigned short*)wp2; a.lo_p2 = lo_p2; a.bp2 = bp2;
+  a.wv1 = (const unsigned short*)wv1; a.lo_v1 = lo_v1; a.bv1 = bv1;
+  a.wv2 = (const unsigned short*)wv2; a.lo_v2 = lo_v2; a.bv2 = bv2;
+  a.logits = logits;
+  a.vlogits = vlogits;
+  a.values = values;
+  a.B = B; a.SK = SK; a.act = act; a.nbp = nbp; a.a_store = a_store; a.logit_stride = logit_stride;
+  a.atoms = atoms; a.atoms_store = atoms_store; a.value_stride = value_stride;
+  a.vmin = vmin; a.dz = dz;
+  hipLaunchKernelGGL(heads_split_kernel, dim3((B + kHeadRowsS - 1) / kHeadRowsS), dim3(256), 0, stream, a);
+  return hip_err(hipGetLastError());
+}
+
+}  // extern "C"

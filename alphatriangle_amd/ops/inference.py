@@ -56,8 +56,26 @@ def _pow2(x: int) -> bool:
 
 def engine_supports(mc: ModelConfig, ec: EnvConfig, dtype: str = "bf16") -> tuple[bool, str]:
     """Whether the HIP engine implements this architecture at this precision (else callers use the PyTorch module)."""
-    if dtype not in ("bf16",):
+    if dtype not in ("bf16", "fp32"):
         return False, f"no {dtype} kernels"
+    if dtype == "fp32":
+        # The fp32-grade kernels (csrc/hip/split_*.hip) are written for the reference's default architecture family:
+        # 3x3 stem 1 -> 32 -> 64 -> 128, 128-channel residual blocks, d_model 128 / 4 heads, 128-wide dense tail.
+        if ec.ROWS > 8 or ec.COLS > 15:
+            return False, "fp32 kernels need a board of at most 8 x 15 cells"
+        if list(mc.CONV_FILTERS) != [32, 64, 128]:
+            return False, "fp32 kernels need the conv stem 32 / 64 / 128"
+        if mc.NUM_RESIDUAL_BLOCKS > 0 and mc.RESIDUAL_BLOCK_FILTERS != 128:
+            return False, "fp32 kernels need 128-channel residual blocks"
+        if mc.USE_TRANSFORMER and mc.TRANSFORMER_LAYERS > 0:
+            if mc.TRANSFORMER_DIM != 128 or mc.TRANSFORMER_HEADS != 4 or mc.TRANSFORMER_FC_DIM % 128 != 0 or mc.TRANSFORMER_FC_DIM > 512:
+                return False, "fp32 kernels need d_model 128, 4 heads and a feed-forward width of 128 / 256 / 384 / 512"
+            if mc.ACTIVATION_FUNCTION not in ("ReLU", "GELU"):
+                return False, "fp32 encoder kernel implements ReLU and GELU"
+        if list(mc.FC_DIMS_SHARED) != [128] or list(mc.POLICY_HEAD_DIMS) != [128] or list(mc.VALUE_HEAD_DIMS) != [128]:
+            return False, "fp32 kernels need the 128-wide dense tail"
+        if mc.NUM_VALUE_ATOMS > 128:
+            return False, "fp32 tail kernel holds at most 128 value atoms"
     if mc.GRID_INPUT_CHANNELS != 1:
         return False, "GRID_INPUT_CHANNELS != 1"
     if not mc.CONV_FILTERS:
@@ -143,6 +161,19 @@ def pack_gemm_weights(w: torch.Tensor, device: torch.device) -> tuple[torch.Tens
     return out, nb_n
 
 
+def pack_gemm_weights_split(w: torch.Tensor, device: torch.device) -> tuple[torch.Tensor, int, int]:
+    """fp32 weights as two packed bf16 fragment streams, ``hi = bf16(w)`` and ``lo = bf16(w - hi)``, concatenated.
+
+    Returns ``(packed, n_blocks, lo_offset_in_elements)``; both streams use the layout of :func:`pack_gemm_weights`.
+    """
+    w32 = w.detach().to(device=device, dtype=torch.float32)
+    hi = w32.to(torch.bfloat16)
+    lo = w32 - hi.float()
+    p_hi, nb = pack_gemm_weights(hi.float(), device)
+    p_lo, _ = pack_gemm_weights(lo, device)
+    return torch.cat([p_hi, p_lo]), nb, int(p_hi.numel())
+
+
 def _fold_bn(weight: torch.Tensor, bias: torch.Tensor | None, bn: nn.Module | None) -> tuple[torch.Tensor, torch.Tensor]:
     """Fold an eval-mode BatchNorm into ``weight`` (out-channel first) and ``bias``."""
     w = weight.detach().float()
@@ -168,6 +199,7 @@ class _GemmLayer:
     ln_b: torch.Tensor | None = None
     ln_eps: float = 1e-5
     post_add: torch.Tensor | None = None
+    lo_off: int = 0   # fp32 mode: element offset of the lo fragment stream inside ``w``
 
 
 def _split_seq(seq: nn.Sequential) -> list[tuple[nn.Module, nn.Module | None, bool]]:
@@ -197,6 +229,7 @@ class InferenceEngine:
             raise ValueError(f"HIP inference engine does not support this config: {why}")
         hb.lib()  # fail loudly when the kernel library is missing
         self.dtype = dtype
+        self.split = dtype == "fp32"  # fp32 activations, every GEMM as three bf16 MFMA passes over (hi, lo) splits
         self.mc = model_config
         self.ec = env_config
         self.device = torch.device(device)
@@ -261,13 +294,17 @@ class InferenceEngine:
     def _gemm(self, w_tkc: torch.Tensor, bias: torch.Tensor, act: int, **kw: Any) -> _GemmLayer:
         taps, cin, cout = w_tkc.shape
         cout8 = (cout + 7) // 8 * 8
-        packed, nb = pack_gemm_weights(w_tkc, self.device)
+        lo_off = 0
+        if self.split:
+            packed, nb, lo_off = pack_gemm_weights_split(w_tkc, self.device)
+        else:
+            packed, nb = pack_gemm_weights(w_tkc, self.device)
         b = torch.zeros(nb * 128, dtype=torch.float32, device=self.device)
         b[:cout] = bias.to(self.device)
         for k in ("ln_g", "ln_b", "post_add"):
             if kw.get(k) is not None:
                 kw[k] = self._put(kw[k])
-        return _GemmLayer(self._put(packed), self._put(b), cin, cout8, taps, act, nb, **kw)
+        return _GemmLayer(self._put(packed), self._put(b), cin, cout8, taps, act, nb, lo_off=lo_off, **kw)
 
     def _conv_layer(self, conv: nn.Conv2d, bn: nn.Module | None, act: int, **kw: Any) -> _GemmLayer:
         w, b = _fold_bn(conv.weight, conv.bias, bn)  # [Cout, Cin, kh, kw]
@@ -319,8 +356,8 @@ class InferenceEngine:
             hd = D // mc.TRANSFORMER_HEADS
             # The fused / row-tiled encoder kernels only normalise; LayerNorm's affine part is folded into the
             # following projection: (xhat * g + b) W = xhat (g (.) W) + b W.  The tile-kernel fallback keeps g / b.
-            fold_attn = self.fused_tf or self.rows_attn
-            fold_ffn = self.fused_ffn
+            fold_attn = self.fused_tf or self.rows_attn or self.split
+            fold_ffn = self.fused_ffn or self.split
             for layer in model.transformer_body.layers:
                 w_in = layer.self_attn.in_proj_weight.detach().float().clone()  # [3D, D]
                 b_in = layer.self_attn.in_proj_bias.detach().float().clone()
@@ -368,7 +405,12 @@ class InferenceEngine:
         wk = torch.cat([wf, wo], dim=1).t().contiguous()  # [Kp, N]
         self.fc_kp = wk.shape[0]
         self.fc_n = wk.shape[1]
-        self.fc_w = self._put(pack_gemm_weights(wk.unsqueeze(0), dev)[0])
+        if self.split:
+            fc_packed, _, self.fc_lo = pack_gemm_weights_split(wk.unsqueeze(0), dev)
+            self.fc_w = self._put(fc_packed)
+        else:
+            self.fc_lo = 0
+            self.fc_w = self._put(pack_gemm_weights(wk.unsqueeze(0), dev)[0])
         self.fc_b = self._put(b)
         self.shared_rest = [self._linear_layer(l, bn, self.act if a else 0) for l, bn, a in shared[1:]]
         self.policy_layers = [self._linear_layer(l, bn, self.act if a else 0) for l, bn, a in _split_seq(model.policy_head)]
@@ -404,6 +446,16 @@ class InferenceEngine:
         if self.uses_tf:
             widths += [3 * self.mc.TRANSFORMER_DIM, self.mc.TRANSFORMER_FC_DIM]
         maxc = max(widths)
+        if self.split:
+            self.bufs = [torch.empty(rows * 128, dtype=torch.float32, device=dev) for _ in range(3)]
+            self.fc_in = self.vt = None
+            self.slabs = torch.empty(self.fc_sk, batch, 128, dtype=torch.float32, device=dev)
+            self.dense = []
+            self.logits = torch.zeros(batch, self.logit_stride, dtype=torch.float32, device=dev)
+            self.vlogits = torch.zeros(batch, self.value_stride, dtype=torch.float32, device=dev)
+            self.values = torch.zeros(batch, dtype=torch.float32, device=dev)
+            self.cap = batch
+            return
         self.bufs = [torch.empty(rows * maxc, dtype=torch.bfloat16, device=dev) for _ in range(5)]
         self.fc_in = None if self.fc_fused else torch.zeros(batch, self.fc_kp, dtype=torch.bfloat16, device=dev)
         self.vt = torch.zeros(batch * 4 * 32 * 256, dtype=torch.bfloat16, device=dev) if self.rows_attn else None
@@ -448,6 +500,51 @@ class InferenceEngine:
             and l1.act == l2.act and l1.post_add is None and l1.ln_g is None and l2.ln_g is None
         )
 
+    def _forward_split(self, grid: torch.Tensor, other: torch.Tensor, B: int) -> tuple[torch.Tensor, torch.Tensor]:
+        """fp32-grade evaluation (csrc/hip/split_*.hip): fp32 activations between launches, one launch per stem /
+        residual block / encoder layer, split-K FC with the final LayerNorm fused, one tail launch."""
+        bufs = self.bufs
+        body = self.body_layers
+        l1, l2 = body[0][1], body[1][1]
+        hb.call("atri_split_conv_stem", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.ptr(l1.w), hb.i64(l1.lo_off),
+                hb.ptr(l1.bias), hb.ptr(l2.w), hb.i64(l2.lo_off), hb.ptr(l2.bias), hb.ptr(l2.post_add), hb.ptr(bufs[0]),
+                hb.i32(B), hb.i32(self.H), hb.i32(self.W), hb.i32(self.c0), hb.i32(l1.cout), hb.i32(l2.cout), hb.i32(self.act))
+        cur = 0
+        rest = body[2:]
+        for li in range(0, len(rest), 2):
+            (ka, la), (kb, lb) = rest[li], rest[li + 1]
+            assert ka == "res_a" and kb == "res_b"
+            dst = (cur + 1) % 3
+            hb.call("atri_split_conv_pair", hb.ptr(bufs[cur]), hb.ptr(la.w), hb.i64(la.lo_off), hb.ptr(la.bias), hb.ptr(lb.w),
+                    hb.i64(lb.lo_off), hb.ptr(lb.bias), hb.ptr(lb.post_add), hb.ptr(bufs[dst]), hb.i32(B), hb.i32(self.H),
+                    hb.i32(self.W), hb.i32(la.cin), hb.i32(la.act))
+            cur = dst
+        ln = None
+        if self.uses_tf:
+            for tl in self.tf_layers:
+                qkv, out, ff1, ff2 = tl["qkv"], tl["out"], tl["ff1"], tl["ff2"]
+                dst = (cur + 1) % 3
+                hb.call("atri_split_encoder_layer", hb.ptr(bufs[cur]), hb.ptr(bufs[dst]), hb.ptr(qkv.w), hb.i64(qkv.lo_off),
+                        hb.ptr(qkv.bias), hb.ptr(out.w), hb.i64(out.lo_off), hb.ptr(out.bias), hb.f32(qkv.ln_eps), hb.ptr(ff1.w),
+                        hb.i64(ff1.lo_off), hb.ptr(ff1.bias), hb.ptr(ff2.w), hb.i64(ff2.lo_off), hb.ptr(ff2.bias), hb.f32(ff1.ln_eps),
+                        hb.i32(B), hb.i32(self.HW), hb.i32(ff1.cout), hb.i32(self.act))
+                cur = dst
+            ln = self.final_ln
+        g, bt, eps = ln if ln is not None else (None, None, 0.0)
+        hb.call("atri_split_fc_rows", hb.ptr(bufs[cur]), hb.ptr(other), hb.i32(self.other_dim), hb.ptr(g), hb.ptr(bt), hb.f32(eps),
+                hb.ptr(self.fc_w), hb.i64(self.fc_lo), hb.ptr(self.slabs), hb.i32(B), hb.i32(self.HW), hb.i32(self.feat_c),
+                hb.i32(self.other_pad), hb.i32(self.fc_n), hb.i32(self.fc_sk), hb.i32(self.fc_steps_per_split))
+        p1, p2 = self.policy_layers
+        v1, v2 = self.value_layers
+        dz = (self.mc.VALUE_MAX - self.mc.VALUE_MIN) / (self.mc.NUM_VALUE_ATOMS - 1)
+        hb.call("atri_split_heads", hb.ptr(self.slabs), hb.i32(self.fc_sk), hb.ptr(self.fc_b), hb.ptr(p1.w), hb.i64(p1.lo_off),
+                hb.ptr(p1.bias), hb.ptr(p2.w), hb.i64(p2.lo_off), hb.ptr(p2.bias), hb.i32(p2.n_blocks), hb.i32(p2.cout),
+                hb.ptr(v1.w), hb.i64(v1.lo_off), hb.ptr(v1.bias), hb.ptr(v2.w), hb.i64(v2.lo_off), hb.ptr(v2.bias),
+                hb.i32(self.mc.NUM_VALUE_ATOMS), hb.i32(v2.cout), hb.ptr(self.logits), hb.i32(self.logit_stride),
+                hb.ptr(self.vlogits), hb.i32(self.value_stride), hb.ptr(self.values), hb.f32(self.mc.VALUE_MIN), hb.f32(dz),
+                hb.i32(B), hb.i32(self.act))
+        return self.logits[:B, : self.A], self.values[:B]
+
     @torch.no_grad()
     def forward(self, grid: torch.Tensor, other: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """``grid`` f32 [B, 1, H, W] (or [B, HW]), ``other`` f32 [B, Do] -> ``(logits [B, A], value [B])``.
@@ -466,6 +563,8 @@ class InferenceEngine:
             other = other.float().contiguous()
         if grid.numel() != B * self.HW or other.numel() != B * self.other_dim:
             raise ValueError("feature tensor shapes do not match the engine configuration")
+        if self.split:
+            return self._forward_split(grid, other, B)
         rows = B * self.HW
         bufs = self.bufs
         cur = 0  # index of the buffer holding the current activation

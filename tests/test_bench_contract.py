@@ -34,15 +34,19 @@ def test_bench_without_gpu_reports_one_json_error_line():
 
 
 @pytest.mark.gpu
-def test_bench_prints_exactly_one_json_line_with_the_contract_fields():
-    res = _run(["--steps", "2", "--warmup", "1", "--games", "512", "--sims", "16", "--train-steps", "2"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_bench_prints_exactly_one_json_line_with_the_contract_fields(dtype):
+    res = _run(["--steps", "2", "--warmup", "1", "--games", "512", "--sims", "16", "--train-steps", "2", "--dtype", dtype])
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
     out = json.loads(lines[0])
     assert REQUIRED <= set(out)
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1
-    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["dtype"] == "bf16"
+    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["dtype"] == dtype
+    assert out["vs_baseline"] is None  # 16 simulations: no reference-style figure exists for this configuration
+    assert out["trainer_samples_per_sec_unthrottled"] > out["trainer_samples_per_sec"]
+    assert 0 < out["leaf_slots_needing_evaluation"] <= 1
     assert out["value"] > 0 and out["ms_per_step"] > 0
     # value = games * steps / elapsed: consistent with the per-step time it reports
     assert abs(out["value"] - 512 / (out["ms_per_step"] / 1e3)) / out["value"] < 0.02

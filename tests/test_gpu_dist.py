@@ -37,8 +37,8 @@ assert g.shape == (1, 64, 64) and torch.equal(g[0], ref[:4096].view(64, 64))
 t = torch.tensor([3.0, 7.0], device=dev)
 assert ctx.all_reduce_max_(t).tolist() == [3.0, 7.0]
 assert ctx.all_reduce_scalar(2.5, "sum") == 2.5 and ctx.all_reduce_scalar(2.5, "max") == 2.5
-ctx.broadcast_weights_async(x)
-assert ctx.finish_weight_broadcast(x) and torch.equal(x, ref)
+assert ctx.agree([1.0, 4.0], "min") == [1.0, 4.0]   # host-side control plane next to the RCCL communicator
+assert ctx.control is not None and ctx.control.add("k", 2) == 2 and ctx.control.peek("none", 5) == 5
 sub = dist.new_group(ranks=[0])                      # the split layout builds sub-groups
 out = [torch.empty(8, device=dev)]
 dist.gather(torch.ones(8, device=dev), gather_list=out, dst=0, group=sub)

@@ -1,0 +1,198 @@
+"""fp32-grade inference engine (csrc/hip/split_*.hip): numerics against fp32 / fp64 PyTorch, and search-level
+equivalence of the three leaf evaluators (bf16 engine, fp32-grade engine, fp32 PyTorch module) on the same device tree.
+
+The reference evaluates in fp32 (reference tests/nn/test_model.py:80-81); these tests pin how close the engine's
+three-pass bf16 MFMA scheme comes to it, and what bf16 evaluation changes in the moves a 400-simulation search picks.
+"""
+
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from alphatriangle_amd.config import AlphaTriangleMCTSConfig, EnvConfig, ModelConfig, SystemConfig, TrainConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomise_norm_layers(model: torch.nn.Module) -> None:
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.normal_(0, 0.2)
+
+
+@pytest.mark.parametrize("preset,act", [("default", "ReLU"), ("cnn", "ReLU"), ("default", "GELU")])
+@pytest.mark.parametrize("batch", [37, 300])
+def test_fp32_engine_is_as_close_to_fp64_as_pytorch_fp32(preset, act, batch):
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(5)
+    dev = torch.device("cuda")
+    env = EnvConfig()
+    mc = (ModelConfig() if preset == "default" else ModelConfig.cnn_only()).model_copy(update={"ACTIVATION_FUNCTION": act})
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev, inference_dtype="fp32")
+    assert net.engine is not None and net.engine.dtype == "fp32", "the fp32-grade HIP engine must be active"
+    _randomise_norm_layers(net._orig_model)
+    net.sync_inference_weights()
+    grid = torch.randint(-1, 2, (batch, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(batch, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    net._orig_model.eval()
+    with torch.no_grad():
+        ref32_l, ref32_v = net._orig_model(grid, other)
+        m64 = copy.deepcopy(net._orig_model).double()
+        ref64_l, ref64_v = m64(grid.double(), other.double())
+    support = net.support.double()
+    val64 = (torch.softmax(ref64_v, 1) * support).sum(1)
+    val32 = (torch.softmax(ref32_v.double(), 1) * support).sum(1)
+    logits, value = net.evaluate_features(grid, other)
+    torch.cuda.synchronize()
+    assert logits.shape == (batch, env.ACTION_DIM) and torch.isfinite(logits).all() and torch.isfinite(value).all()
+    eng_err = (logits.double() - ref64_l).abs().max().item()
+    t32_err = (ref32_l.double() - ref64_l).abs().max().item()
+    scale = ref64_l.abs().max().item()
+    veng = (value.double() - val64).abs().max().item()
+    vt32 = (val32 - val64).abs().max().item()
+    print(f"[{preset}/{act}/B={batch}] logits: engine {eng_err:.3e}, torch fp32 {t32_err:.3e} (scale {scale:.2f}); "
+          f"value: engine {veng:.3e}, torch fp32 {vt32:.3e}")
+    # the engine's distance to the fp64 result is of the order of PyTorch fp32's own distance, four orders of magnitude
+    # below what the bf16 engine is allowed (0.05 * scale + 0.03 in tests/test_gpu_nn.py)
+    assert eng_err < 2e-4 * max(scale, 1.0), f"logit error {eng_err} vs fp64 (torch fp32: {t32_err})"
+    assert veng < 2e-4, f"value error {veng} vs fp64 (torch fp32: {vt32})"
+    assert (logits.argmax(1) == ref64_l.argmax(1)).float().mean().item() >= 0.99
+
+
+def test_fp32_engine_ignores_rows_beyond_the_batch_and_handles_small_boards():
+    """Partial workgroups (batch not a multiple of the tile sizes) and a 5x6 board (30 tokens, padded key tiles)."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(6)
+    dev = torch.device("cuda")
+    env = EnvConfig(ROWS=5, COLS=6, PLAYABLE_RANGE_PER_ROW=[(0, 6)] * 5, NUM_SHAPE_SLOTS=2)
+    mc = ModelConfig(OTHER_NN_INPUT_FEATURES_DIM=8 * 2 + 6)
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev, inference_dtype="fp32")
+    assert net.engine is not None and net.engine.dtype == "fp32"
+    _randomise_norm_layers(net._orig_model)
+    net.sync_inference_weights()
+    for batch in (1, 17, 65):
+        grid = torch.randint(-1, 2, (batch, 1, env.ROWS, env.COLS), device=dev).float()
+        other = torch.rand(batch, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+        net._orig_model.eval()
+        with torch.no_grad():
+            ref_l, ref_v = net._orig_model(grid, other)
+            ref_val = net._logits_to_expected_value(ref_v).squeeze(1)
+        logits, value = net.evaluate_features(grid, other)
+        torch.cuda.synchronize()
+        assert (logits - ref_l).abs().max().item() < 3e-4 * max(1.0, ref_l.abs().max().item())
+        assert (value - ref_val).abs().max().item() < 3e-4
+
+
+def _briefly_trained_network(dtype: str):
+    """The default network after a short self-play + training run (weights away from their initialisation)."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.rl.core.device_buffer import DeviceReplayBuffer
+    from alphatriangle_amd.rl.core.trainer import Trainer
+    from alphatriangle_amd.rl.self_play.gpu_actor import GpuSelfPlayActor
+
+    torch.manual_seed(11)
+    dev = torch.device("cuda")
+    env, mc = EnvConfig(), ModelConfig()
+    tc = TrainConfig(DEVICE="cuda", BUFFER_CAPACITY=50_000, MIN_BUFFER_SIZE_TO_TRAIN=512, BATCH_SIZE=128, N_STEP_RETURNS=3,
+                     MAX_TRAINING_STEPS=1000, LEARNING_RATE=1e-3, COMPILE_MODEL=False)
+    sc = SystemConfig(GAMES_PER_GPU=512, INFERENCE_DTYPE=dtype, REPLAY_HBM_BUDGET_GB=4.0)
+    net = NeuralNetwork(mc, env, tc, dev, inference_dtype=dtype)
+    replay = DeviceReplayBuffer(tc, env, mc, dev, sc)
+    actor = GpuSelfPlayActor(env, mc, AlphaTriangleMCTSConfig(max_simulations=24, max_depth=6), tc, sc, net, replay, dev, seed=5)
+    trainer = Trainer(net, tc, env, autocast_bf16=False)
+    step = 0
+    for move in range(12):
+        actor.play_move()
+        if len(replay) >= tc.MIN_BUFFER_SIZE_TO_TRAIN:
+            for _ in range(6):
+                batch = replay.sample(tc.BATCH_SIZE, current_train_step=step)
+                _, td = trainer.train_step_tensors(batch)
+                replay.update_priorities(batch.indices, td)
+                step += 1
+            actor.sync_weights(step)
+    assert step >= 30
+    roots = actor.tree.current_root_states().clone()  # 512 positions, 12 moves into their games
+    del actor, replay, trainer
+    return net, roots, env, mc
+
+
+def _search(env, mcts, roots, evaluate, logits, values, other_dim):
+    from alphatriangle_amd.ops.engine import GpuTreeEngine
+
+    dev = roots.device
+    G = roots.shape[0]
+    tree = GpuTreeEngine(env, mcts, dev, G, 1, other_dim, logits, values, seed=1)
+    tree.set_roots(roots)
+    tree.prepare_roots()
+    evaluate(tree.nn_grid, tree.nn_other)
+    tree.init_roots()
+    for w in range(mcts.max_simulations):
+        tree.wave(consume=w > 0, select=True)
+        evaluate(tree.nn_grid, tree.nn_other)
+    tree.wave(consume=True, select=False)
+    visits = tree.root_visits().double()
+    torch.cuda.synchronize()
+    del tree
+    return visits
+
+
+def test_search_picks_the_same_moves_under_bf16_fp32_engine_and_fp32_module():
+    """256 positions x 400 simulations on the same device tree, leaves evaluated three ways.
+
+    Reference precision is the fp32 PyTorch module.  The fp32-grade engine has to reproduce its searches almost
+    exactly; the bf16 engine has to pick the same move (most visited root action) in at least 95 % of the positions with
+    a small KL divergence between the root visit distributions.
+    """
+    from alphatriangle_amd.ops.inference import InferenceEngine
+    from alphatriangle_amd.rl.self_play.gpu_actor import ModuleEvaluator
+
+    net, roots, env, mc = _briefly_trained_network("bf16")
+    dev = roots.device
+    G = 256
+    roots = roots[:G].contiguous()
+    mcts = AlphaTriangleMCTSConfig(max_simulations=400, max_depth=8, dirichlet_epsilon=0.0)
+    other_dim = mc.OTHER_NN_INPUT_FEATURES_DIM
+
+    eng16 = net.engine
+    assert eng16 is not None and eng16.dtype == "bf16"
+    eng16.reserve(G)
+    v16 = _search(env, mcts, roots, eng16.forward, eng16.logits, eng16.values, other_dim)
+
+    eng32 = InferenceEngine(mc, env, dev, dtype="fp32")
+    eng32.load_from_module(net._orig_model)
+    eng32.reserve(G)
+    v32 = _search(env, mcts, roots, eng32.forward, eng32.logits, eng32.values, other_dim)
+
+    mod = ModuleEvaluator(net, G)
+    vref = _search(env, mcts, roots, mod.forward, mod.logits, mod.values, other_dim)
+
+    live = vref.sum(1) > 0
+    assert live.float().mean().item() > 0.9
+
+    def compare(v):
+        same = (v.argmax(1) == vref.argmax(1))[live].float().mean().item()
+        p = vref[live] / vref[live].sum(1, keepdim=True)
+        q = v[live] / v[live].sum(1, keepdim=True).clamp_min(1)
+        eps = 1e-9
+        kl = (p * ((p + eps) / (q + eps)).log()).sum(1)
+        return same, kl.mean().item(), kl.max().item()
+
+    s32, kl32, klmax32 = compare(v32)
+    s16, kl16, klmax16 = compare(v16)
+    print(f"fp32 engine vs fp32 module: same move {s32:.4f}, mean KL {kl32:.3e}, max KL {klmax32:.3e}")
+    print(f"bf16 engine vs fp32 module: same move {s16:.4f}, mean KL {kl16:.3e}, max KL {klmax16:.3e}")
+    assert s32 >= 0.99 and kl32 < 5e-3
+    assert s16 >= 0.95 and kl16 < 0.05
