@@ -150,6 +150,22 @@ class StatsActor:
         """Fast path without building an event object."""
         return bool(self._ring.push(self._names.id(name), float(value), int(global_step), time.time(), [], []))
 
+    def log_array(self, name: str, values: Any, global_step: int) -> int:
+        """Thousands of samples of one metric in one call (per-game-step metrics of the GPU actor: one value per game).
+
+        The samples go straight into the aggregator - same aggregation as the same number of ``log_event`` calls,
+        without one Python object and one ring slot per sample.  Non-finite samples are dropped.
+        """
+        import numpy as np
+
+        arr = np.asarray(values, dtype=np.float64).reshape(-1)
+        arr = arr[np.isfinite(arr)]
+        if arr.size == 0:
+            return 0
+        with self._agg_lock:
+            self._agg.add_many(name, arr.tolist(), int(global_step))
+        return int(arr.size)
+
     def log_batch_events(self, events: list[RawMetricEvent]) -> int:
         return sum(1 for e in events if self.log_event(e))
 

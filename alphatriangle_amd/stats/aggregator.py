@@ -44,6 +44,19 @@ class StatsAggregator:
             p.values.append(v)
             p.last_step = max(p.last_step, int(ev.global_step))
 
+    def add_many(self, name: str, values, global_step: int) -> None:  # noqa: ANN001
+        """One sample per element of ``values`` for every metric fed by event ``name`` (context-keyed metrics excluded)."""
+        vals = [float(v) for v in values]
+        if not vals:
+            return
+        self.events_seen += len(vals)
+        for m in self._by_event.get(name, ()):
+            if m.context_key is not None:
+                continue
+            p = self._pending[m.name]
+            p.values.extend(vals)
+            p.last_step = max(p.last_step, int(global_step))
+
     def collect(self, global_step: int, force: bool = False) -> list[tuple[MetricConfig, float, int]]:
         """Return ``(metric, value, step)`` for every metric that is due."""
         now = time.monotonic()

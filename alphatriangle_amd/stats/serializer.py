@@ -6,12 +6,20 @@ checkpoint ``{run_name, global_step, episodes_played, total_simulations_run,
 model_state_dict, optimizer_state_dict, model_config_dict, env_config_dict}`` and
 buffer ``{buffer_list: list[Experience]}`` with
 ``Experience = ({"grid": f32[C,H,W], "other_features": f32[D]}, {action: prob}, float)``.
-Loading accepts these classes, plain dicts, or any object exposing the same attribute names.
+
+Files are written as PLAIN dictionaries of builtins, tensors and arrays (field names above plus a
+``format`` tag): the pickle stream then names no class of this project, so any stack that knows the
+field names can read it.  Loading accepts that form, the pydantic objects earlier versions of this
+package wrote, and streams that name the reference stack's classes (``trieye.schemas.CheckpointData``
+/ ``BufferData`` / ``LoadedTrainingState``, resolved to the classes below by an aliasing unpickler;
+alphatriangle/training/runner.py:36-79 is the reference's consumer of these objects).
 """
 
 from __future__ import annotations
 
+import io
 import logging
+import pickle
 from pathlib import Path
 from typing import Any
 
@@ -85,6 +93,32 @@ def _experience_ok(exp: Any) -> bool:
         return False
 
 
+CHECKPOINT_FORMAT = "alphatriangle-checkpoint/1"
+BUFFER_FORMAT = "alphatriangle-buffer/1"
+
+# class paths other stacks (or earlier versions of this one) may have pickled by reference -> the classes above
+_CLASS_ALIASES = {
+    "CheckpointData": CheckpointData,
+    "BufferData": BufferData,
+    "LoadedTrainingState": LoadedTrainingState,
+}
+_ALIAS_MODULE_PREFIXES = ("trieye", "alphatriangle_amd.stats", "alphatriangle.")
+
+
+class _AliasUnpickler(pickle.Unpickler):
+    """``pickle.Unpickler`` that resolves the schema classes of the reference stack to the in-repo ones."""
+
+    def find_class(self, module: str, name: str) -> Any:
+        if name in _CLASS_ALIASES and module.startswith(_ALIAS_MODULE_PREFIXES):
+            return _CLASS_ALIASES[name]
+        return super().find_class(module, name)
+
+
+def _load_pickle(path: Path) -> Any:
+    with open(path, "rb") as fh:
+        return _AliasUnpickler(io.BytesIO(fh.read())).load()
+
+
 class Serializer:
     """CPU-ifies training state and reads / writes the pickle files."""
 
@@ -113,14 +147,14 @@ class Serializer:
     def save_checkpoint(self, data: CheckpointData, path: Path) -> None:
         path.parent.mkdir(parents=True, exist_ok=True)
         tmp = path.with_suffix(path.suffix + ".tmp")
+        payload = {"format": CHECKPOINT_FORMAT, **data.model_dump()}
         with open(tmp, "wb") as fh:
-            cloudpickle.dump(data, fh)
+            cloudpickle.dump(payload, fh)
         tmp.replace(path)
 
     def load_checkpoint(self, path: Path) -> CheckpointData | None:
         try:
-            with open(path, "rb") as fh:
-                obj = cloudpickle.load(fh)
+            obj = _load_pickle(path)
         except Exception as exc:
             logger.error("Failed to load checkpoint %s: %s", path, exc)
             return None
@@ -130,13 +164,12 @@ class Serializer:
         path.parent.mkdir(parents=True, exist_ok=True)
         tmp = path.with_suffix(path.suffix + ".tmp")
         with open(tmp, "wb") as fh:
-            cloudpickle.dump(data, fh)
+            cloudpickle.dump({"format": BUFFER_FORMAT, "buffer_list": list(data.buffer_list)}, fh)
         tmp.replace(path)
 
     def load_buffer(self, path: Path) -> BufferData | None:
         try:
-            with open(path, "rb") as fh:
-                obj = cloudpickle.load(fh)
+            obj = _load_pickle(path)
         except Exception as exc:
             logger.error("Failed to load buffer %s: %s", path, exc)
             return None
@@ -151,6 +184,11 @@ class Serializer:
     def _coerce_checkpoint(obj: Any) -> CheckpointData | None:
         if isinstance(obj, CheckpointData):
             return obj
+        if isinstance(obj, LoadedTrainingState):
+            return obj.checkpoint_data
+        inner = obj.get("checkpoint_data") if isinstance(obj, dict) else getattr(obj, "checkpoint_data", None)
+        if inner is not None:  # a whole loaded-state object: the checkpoint is one level down
+            return Serializer._coerce_checkpoint(inner)
         get = (lambda k, d=None: obj.get(k, d)) if isinstance(obj, dict) else (lambda k, d=None: getattr(obj, k, d))
         try:
             return CheckpointData(

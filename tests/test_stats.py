@@ -154,3 +154,89 @@ def test_serializer_accepts_plain_dict_checkpoints(tmp_path):
     assert Serializer().load_checkpoint(tmp_path / "missing.pkl") is None
     pc = PersistenceConfig(APP_NAME="A", RUN_NAME="r")
     assert pc.get_runs_root_dir().name == "runs" and pc.MLFLOW_TRACKING_URI.startswith("file://") and pc.get_mlflow_abs_path().name == "mlruns"
+
+
+def test_checkpoint_files_name_no_project_class_and_reference_class_paths_resolve(tmp_path):
+    """Interop with the reference stack's files (alphatriangle/training/runner.py:36-79 consumes
+    ``LoadedTrainingState{checkpoint_data, buffer_data}`` objects of the external ``trieye`` package): what this
+    package writes is a plain dict, and a stream that names ``trieye.schemas.*`` classes loads into the in-repo ones.
+    The foreign file is fabricated here (no file of the reference is loaded); parity with real reference pickles is
+    unpinned because none ships with the reference."""
+    import pickle
+    import sys
+    import types
+
+    import cloudpickle
+    import torch
+    from pydantic import BaseModel, ConfigDict
+
+    from alphatriangle_amd.stats.serializer import BufferData, CheckpointData, Serializer
+
+    ser = Serializer()
+    ck = CheckpointData(run_name="r", global_step=7, episodes_played=3, total_simulations_run=99,
+                        model_state_dict={"w": torch.arange(4.0)}, optimizer_state_dict={"state": {}, "param_groups": []})
+    path = tmp_path / "ck.pkl"
+    ser.save_checkpoint(ck, path)
+    raw = path.read_bytes()
+    assert b"alphatriangle_amd" not in raw and b"pydantic" not in raw  # only builtins, torch and numpy in the stream
+    plain = pickle.loads(raw)
+    assert isinstance(plain, dict) and plain["global_step"] == 7 and torch.equal(plain["model_state_dict"]["w"], torch.arange(4.0))
+    back = ser.load_checkpoint(path)
+    assert back.global_step == 7 and back.episodes_played == 3 and torch.equal(back.model_state_dict["w"], torch.arange(4.0))
+    exp = ({"grid": np.zeros((1, 3, 3), np.float32), "other_features": np.ones(14, np.float32)}, {0: 1.0}, 0.5)
+    bpath = tmp_path / "buf.pkl"
+    ser.save_buffer(BufferData(buffer_list=[exp]), bpath)
+    assert b"alphatriangle_amd" not in bpath.read_bytes() and len(ser.load_buffer(bpath).buffer_list) == 1
+
+    # a file as the reference stack's service would write it: pydantic objects pickled by reference to trieye.schemas
+    mod = types.ModuleType("trieye.schemas")
+
+    class _Base(BaseModel):
+        model_config = ConfigDict(arbitrary_types_allowed=True, protected_namespaces=())
+
+    class ForeignCheckpoint(_Base):
+        run_name: str
+        global_step: int
+        episodes_played: int
+        total_simulations_run: int
+        model_config_dict: dict = {}
+        env_config_dict: dict = {}
+        model_state_dict: dict = {}
+        optimizer_state_dict: dict = {}
+
+    class ForeignBuffer(_Base):
+        buffer_list: list = []
+
+    for cls, name in ((ForeignCheckpoint, "CheckpointData"), (ForeignBuffer, "BufferData")):
+        cls.__module__, cls.__qualname__, cls.__name__ = "trieye.schemas", name, name
+        setattr(mod, name, cls)
+    pkg = types.ModuleType("trieye")
+    pkg.schemas = mod
+    sys.modules["trieye"], sys.modules["trieye.schemas"] = pkg, mod
+    try:
+        fck, fbuf = tmp_path / "foreign_ck.pkl", tmp_path / "foreign_buf.pkl"
+        with open(fck, "wb") as fh:
+            cloudpickle.dump(ForeignCheckpoint(run_name="ref", global_step=11, episodes_played=5, total_simulations_run=640,
+                                               model_state_dict={"w": torch.ones(2)}), fh)
+        with open(fbuf, "wb") as fh:
+            cloudpickle.dump(ForeignBuffer(buffer_list=[exp, exp]), fh)
+        assert b"trieye.schemas" in fck.read_bytes()  # pickled by reference to the foreign class path
+    finally:
+        del sys.modules["trieye"], sys.modules["trieye.schemas"]
+    got = ser.load_checkpoint(fck)  # the trieye package is not importable any more: the alias has to resolve the class
+    assert isinstance(got, CheckpointData) and got.run_name == "ref" and got.global_step == 11 and torch.equal(got.model_state_dict["w"], torch.ones(2))
+    assert len(ser.load_buffer(fbuf).buffer_list) == 2
+
+
+def test_log_array_counts_one_sample_per_element(tmp_path):
+    from alphatriangle_amd.stats import StatsActor, TrieyeConfig
+
+    cfg = TrieyeConfig(app_name="T", run_name="arr")
+    cfg.persistence.ROOT_DATA_DIR = str(tmp_path)
+    actor = StatsActor(cfg, start_threads=False)
+    assert actor.log_array("step_reward", np.array([1.0, 2.0, np.nan, 3.0]), 5) == 3
+    assert actor.force_process_and_log(5) >= 1
+    lines = [json.loads(ln) for ln in (tmp_path / "T" / "runs" / "arr" / "metrics.jsonl").read_text().splitlines()]
+    rewards = [ln for ln in lines if "reward" in ln["name"].lower()]
+    assert rewards and any(abs(ln["value"] - 2.0) < 1e-9 for ln in rewards)  # mean of the three finite samples
+    actor.shutdown(timeout=2.0)
