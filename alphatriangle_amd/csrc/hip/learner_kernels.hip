@@ -462,17 +462,18 @@ void ln_bwd_launch(const void* x, const void* dy, const float* g, const float* m
 // shared by the taps; every store is 16 bytes, coalesced along the row).
 constexpr int kPatchCols = 2048;
 
-template <int KH, int KW>
-__global__ __launch_bounds__(256) void patch_matrix_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ cols,
+template <typename T, int KH, int KW>
+__global__ __launch_bounds__(256) void patch_matrix_kernel(const T* __restrict__ x, T* __restrict__ cols,
                                                           int B, int H, int W, int ph, int pw, int oh, int ow) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short tile[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  T* tile = reinterpret_cast<T*>(tile_raw);
   const int c = blockIdx.y, tid = threadIdx.x;
   const int plane = oh * ow, n_total = B * plane;
   const int n_begin = blockIdx.x * kPatchCols, n_end = min(n_total, n_begin + kPatchCols);
   const int b_lo = n_begin / plane, b_hi = (n_end - 1) / plane;
   const int board = H * W, count = (b_hi - b_lo + 1) * board;
-  const unsigned short* src = x + ((size_t)c * B + b_lo) * board;
-  if (((((size_t)c * B + b_lo) * board) & 1) == 0) {  // run starts on a 4-byte boundary: dword loads
+  const T* src = x + ((size_t)c * B + b_lo) * board;
+  if (sizeof(T) == 2 && ((((size_t)c * B + b_lo) * board) & 1) == 0) {  // 2-byte elements on a 4-byte boundary: dword loads
     const unsigned* src2 = reinterpret_cast<const unsigned*>(src);
     unsigned* tile2 = reinterpret_cast<unsigned*>(tile);
     for (int i = tid; i < (count >> 1); i += 256) tile2[i] = src2[i];
@@ -501,38 +502,47 @@ __global__ __launch_bounds__(256) void patch_matrix_kernel(const unsigned short*
     }
   }
   const size_t row_pitch = (size_t)n_total;
-  unsigned short* out = cols + (size_t)c * KH * KW * row_pitch + n0;
+  T* out = cols + (size_t)c * KH * KW * row_pitch + n0;
 #pragma unroll
   for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
     for (int kx = 0; kx < KW; ++kx) {
-      unsigned short v[8];
+      T v[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int yy = iy[i] + ky, xx = ix[i] + kx;
         const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        v[i] = in ? tile[base[i] + ky * W + kx] : (unsigned short)0;
+        v[i] = in ? tile[base[i] + ky * W + kx] : (T)0;
       }
-      uint4 o;
-      o.x = v[0] | ((unsigned)v[1] << 16);
-      o.y = v[2] | ((unsigned)v[3] << 16);
-      o.z = v[4] | ((unsigned)v[5] << 16);
-      o.w = v[6] | ((unsigned)v[7] << 16);
-      *reinterpret_cast<uint4*>(out + (size_t)(ky * KW + kx) * row_pitch) = o;
+      T* o = out + (size_t)(ky * KW + kx) * row_pitch;
+      if (sizeof(T) == 2) {
+        uint4 q;
+        q.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+        q.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+        q.z = (unsigned)v[4] | ((unsigned)v[5] << 16);
+        q.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
+        *reinterpret_cast<uint4*>(o) = q;
+      } else {
+        float4 q0, q1;
+        q0.x = (float)v[0]; q0.y = (float)v[1]; q0.z = (float)v[2]; q0.w = (float)v[3];
+        q1.x = (float)v[4]; q1.y = (float)v[5]; q1.z = (float)v[6]; q1.w = (float)v[7];
+        reinterpret_cast<float4*>(o)[0] = q0;
+        reinterpret_cast<float4*>(o)[1] = q1;
+      }
     }
 }
 
-template <int KH, int KW>
+template <typename T, int KH, int KW>
 static int launch_patch_matrix(const void* x, void* cols, int C, int B, int H, int W, int ph, int pw, hipStream_t s) {
   const int oh = H + 2 * ph - KH + 1, ow = W + 2 * pw - KW + 1;
   if (oh <= 0 || ow <= 0 || (((long long)B * oh * ow) & 7) != 0) return -2;
   if ((long long)C * B * H * W > 0x7fffffffLL || (long long)B * oh * ow > 0x7fffffffLL || C > 65535) return -3;
   const int n_total = B * oh * ow;
   const int boards = kPatchCols / (oh * ow) + 2;  // most boards one workgroup's columns can touch
-  const size_t lds = ((size_t)boards * H * W * 2 + 15) & ~(size_t)15;
+  const size_t lds = ((size_t)boards * H * W * sizeof(T) + 15) & ~(size_t)15;
   if (lds > 64 * 1024) return -4;
-  hipLaunchKernelGGL((patch_matrix_kernel<KH, KW>), dim3((n_total + kPatchCols - 1) / kPatchCols, C), dim3(256), lds, s,
-                     (const unsigned short*)x, (unsigned short*)cols, B, H, W, ph, pw, oh, ow);
+  hipLaunchKernelGGL((patch_matrix_kernel<T, KH, KW>), dim3((n_total + kPatchCols - 1) / kPatchCols, C), dim3(256), lds, s,
+                     (const T*)x, (T*)cols, B, H, W, ph, pw, oh, ow);
   return (int)hipGetLastError();
 }
 
@@ -657,12 +667,17 @@ int atri_ln_bwd(const void* x, const void* dy, int is_bf16, const float* g, cons
   return (int)hipGetLastError();
 }
 
-// cols [C*kh*kw, B*oh*ow] = patch matrix of x [C, B, H, W] (bf16, stride 1, zero padding ph / pw); 3x3 and 5x5 kernels.
-int atri_patch_matrix(const void* x, void* cols, int C, int B, int H, int W, int kh, int kw, int ph, int pw, hipStream_t s) {
+// cols [C*kh*kw, B*oh*ow] = patch matrix of x [C, B, H, W] (bf16 or f32, stride 1, zero padding ph / pw); 3x3 and 5x5 kernels.
+int atri_patch_matrix(const void* x, void* cols, int is_bf16, int C, int B, int H, int W, int kh, int kw, int ph, int pw, hipStream_t s) {
   if (C <= 0 || B <= 0) return 0;
   if (ph < 0 || pw < 0 || ph >= kh || pw >= kw) return -1;
-  if (kh == 3 && kw == 3) return launch_patch_matrix<3, 3>(x, cols, C, B, H, W, ph, pw, s);
-  if (kh == 5 && kw == 5) return launch_patch_matrix<5, 5>(x, cols, C, B, H, W, ph, pw, s);
+  if (is_bf16) {
+    if (kh == 3 && kw == 3) return launch_patch_matrix<unsigned short, 3, 3>(x, cols, C, B, H, W, ph, pw, s);
+    if (kh == 5 && kw == 5) return launch_patch_matrix<unsigned short, 5, 5>(x, cols, C, B, H, W, ph, pw, s);
+  } else {
+    if (kh == 3 && kw == 3) return launch_patch_matrix<float, 3, 3>(x, cols, C, B, H, W, ph, pw, s);
+    if (kh == 5 && kw == 5) return launch_patch_matrix<float, 5, 5>(x, cols, C, B, H, W, ph, pw, s);
+  }
   return -1;
 }
 

@@ -152,6 +152,52 @@ class _ConvGemmCM(torch.autograd.Function):
         return d_x, d_w, None, None
 
 
+class _BnActCM(torch.autograd.Function):
+    """Training-mode BatchNorm2d (+ skip connection) (+ activation) on a channel-major activation ``[C, B, H, W]``.
+
+    One fused forward (two launches: statistics, apply) and one fused backward (two launches) through
+    ``ops.hip_learner.bn_act_cm_*`` replace the library BatchNorm call, the skip add and the activation kernel of
+    alphatriangle/nn/model.py:15-60 and their three backward kernels.  The activation's pre-image is recomputed in
+    the backward pass from the saved input, so only per-channel statistics are stored besides what autograd keeps
+    alive anyway.
+    """
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, bn, act_id):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        w32, b32 = weight.float().contiguous(), bias.float().contiguous()
+        momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+        track = bn.track_running_stats and bn.running_mean is not None
+        y, mean, rstd = hip_learner.bn_act_cm_forward(
+            x, residual, w32, b32, float(bn.eps), momentum, bn.running_mean if track else None,
+            bn.running_var if track else None, bn.num_batches_tracked if track else None, act_id,
+        )
+        ctx.save_for_backward(x, residual if residual is not None else x.new_empty(0), w32, b32, mean, rstd)
+        ctx.has_res = residual is not None
+        ctx.act_id = act_id
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        x, res, w32, b32, mean, rstd = ctx.saved_tensors
+        dx, dr, dg, db = hip_learner.bn_act_cm_backward(
+            x.contiguous(), res.contiguous() if ctx.has_res else None, grad_out.to(x.dtype), w32, b32, mean, rstd, ctx.act_id
+        )
+        return dx, dr, dg, db, None, None
+
+
+def _act_id(mod: nn.Module | None) -> int | None:
+    """Activation code of the fused BatchNorm kernels (``None``: not a fusable activation)."""
+    if mod is None or isinstance(mod, nn.Identity):
+        return 0
+    if getattr(mod, "approximate", "none") != "none":  # tanh-approximated GELU is not what the kernels compute
+        return None
+    return {nn.ReLU: 1, nn.GELU: 2, nn.SiLU: 3, nn.Tanh: 4, nn.Sigmoid: 5}.get(type(mod))
+
+
 class GemmConv2d(nn.Conv2d):
     """``nn.Conv2d`` (same parameters, same ``state_dict`` keys) whose GPU path is im2col + GEMM.
 
@@ -500,10 +546,13 @@ class AlphaTriangleNet(nn.Module):
     channel_major = True  # learner fast path: convolution body on [C, B, H, W] activations (tests flip this)
 
     def _cm_plan_ok(self, grid_state: torch.Tensor) -> bool:
-        """The channel-major convolution body needs a GPU, bf16 autocast, the patch-matrix kernel and eligible layers."""
+        """The channel-major convolution body needs a GPU (fp32, or bf16 autocast), the patch-matrix kernel and eligible layers."""
         if not (self.channel_major and grid_state.is_cuda and grid_state.dim() == 4):
             return False
-        if not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        if torch.is_autocast_enabled("cuda"):
+            if torch.get_autocast_dtype("cuda") != torch.bfloat16:
+                return False
+        elif grid_state.dtype != torch.float32:
             return False
         from ..ops import hip_learner
 
@@ -518,21 +567,46 @@ class AlphaTriangleNet(nn.Module):
                 w = w + 2 * m.padding[1] - m.kernel_size[1] + 1
         return True
 
+    fused_batch_norm = True  # learner fast path: BatchNorm (+ skip) (+ activation) as one fused op (tests flip this)
+
+    def _bn_fused_ok(self, bn: nn.Module, x: torch.Tensor, act: nn.Module | None) -> bool:
+        from ..ops import hip_learner
+
+        return bool(
+            self.fused_batch_norm and isinstance(bn, nn.BatchNorm2d) and bn.training and bn.affine and _act_id(act) is not None
+            and torch.is_grad_enabled() and hip_learner.bn_act_cm_supported(x)
+        )
+
     def _cm_apply(self, mod: nn.Module, x: torch.Tensor) -> torch.Tensor:
         """``mod`` on a channel-major activation ``[C, B, H, W]`` (same parameters, buffers and statistics)."""
         if isinstance(mod, nn.Sequential):
-            for m in mod:
+            mods = list(mod)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                fuse_act = nxt is not None and not isinstance(nxt, (nn.Conv2d, nn.BatchNorm2d)) and _act_id(nxt) not in (None, 0)
+                if isinstance(m, nn.BatchNorm2d) and self._bn_fused_ok(m, x, nxt if fuse_act else None):
+                    # BatchNorm followed by an activation: one fused op
+                    x = _BnActCM.apply(x, None, m.weight, m.bias, m, _act_id(nxt) if fuse_act else 0)
+                    i += 2 if fuse_act else 1
+                    continue
                 x = self._cm_apply(m, x)
+                i += 1
             return x
         if isinstance(mod, GemmConv2d):
             return mod.cm_forward(x)
         if isinstance(mod, nn.BatchNorm2d):
+            if self._bn_fused_ok(mod, x, None):
+                return _BnActCM.apply(x, None, mod.weight, mod.bias, mod, 0)
             # per-channel statistics over (B, H, W): the channel-major buffer viewed as ONE image of B*H rows
             c, b, h, w = x.shape
             return mod(x.reshape(1, c, b * h, w)).view(c, b, h, w)
         if isinstance(mod, ResidualBlock):
-            y = self._cm_apply(mod.bn2, self._cm_apply(mod.conv2, self._cm_apply(mod.conv1, x)))
-            return mod.activation(y + x)
+            y = self._cm_apply(mod.conv2, self._cm_apply(mod.conv1, x))
+            if self._bn_fused_ok(mod.bn2, y, mod.activation):
+                return _BnActCM.apply(y, x, mod.bn2.weight, mod.bn2.bias, mod.bn2, _act_id(mod.activation))  # bn2 + skip + activation
+            return mod.activation(self._cm_apply(mod.bn2, y) + x)
         return mod(x)  # activations and Identity are layout-agnostic
 
     def body_channel_major(self, grid_state: torch.Tensor) -> torch.Tensor:

@@ -2,6 +2,8 @@
 
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 from .. import native
@@ -151,9 +153,60 @@ def per_priorities(tree: torch.Tensor, P: int, idx: torch.Tensor, err: torch.Ten
     hb.call("atri_per_priorities", hb.ptr(tree), hb.i64(P), hb.ptr(idx), hb.ptr(err), hb.i32(idx.numel()), hb.f32(alpha), hb.f32(eps), hb.ptr(max_prio))
 
 
+# ---------------------------------------------------------------- fused BatchNorm (+ skip) (+ activation), channel-major
+ACT_IDS = {"Identity": 0, "ReLU": 1, "GELU": 2, "SiLU": 3, "Tanh": 4, "Sigmoid": 5}
+
+
+def bn_act_cm_supported(x: torch.Tensor) -> bool:
+    return bool(x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() >= 2 and (x[0].numel() % 8) == 0
+                and x.shape[0] <= 65535 and available())
+
+
+def _bn_partial(c: int, n: int, device: torch.device) -> torch.Tensor:
+    fn = getattr(hb.lib(), "atri_bn_cm_partial_floats")
+    fn.restype = C.c_int
+    return torch.empty(int(fn(C.c_int(c), C.c_int(n))), dtype=torch.float32, device=device)
+
+
+def bn_act_cm_forward(x: torch.Tensor, residual: torch.Tensor | None, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                      momentum: float, running_mean: torch.Tensor | None, running_var: torch.Tensor | None,
+                      num_batches: torch.Tensor | None, act: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Training-mode BatchNorm over channel-major ``x [C, ...]`` (+ ``residual``) (+ activation) in two launches.
+
+    Returns ``(y, batch_mean, batch_rstd)``; the running statistics and the batch counter are updated in place.
+    """
+    x = x.contiguous()
+    c = int(x.shape[0])
+    n = x.numel() // c
+    y = torch.empty_like(x)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    r = residual.contiguous() if residual is not None else None
+    hb.call("atri_bn_cm_fwd", hb.ptr(x), hb.ptr(r), hb.i32(1 if x.dtype == torch.bfloat16 else 0), hb.ptr(gamma), hb.ptr(beta),
+            hb.ptr(_bn_partial(c, n, x.device)), hb.i32(c), hb.i32(n), hb.f32(eps), hb.f32(momentum), hb.ptr(running_mean),
+            hb.ptr(running_var), hb.ptr(num_batches), hb.ptr(y), hb.ptr(mean), hb.ptr(rstd), hb.i32(act))
+    return y, mean, rstd
+
+
+def bn_act_cm_backward(x: torch.Tensor, residual: torch.Tensor | None, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                       mean: torch.Tensor, rstd: torch.Tensor, act: int) -> tuple[torch.Tensor, torch.Tensor | None, torch.Tensor, torch.Tensor]:
+    """Backward of :func:`bn_act_cm_forward`: ``(dx, d_residual, dgamma, dbeta)`` in two launches."""
+    c = int(x.shape[0])
+    n = x.numel() // c
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    dr = torch.empty_like(x) if residual is not None else None
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    hb.call("atri_bn_cm_bwd", hb.ptr(x), hb.ptr(residual), hb.ptr(dy), hb.i32(1 if x.dtype == torch.bfloat16 else 0), hb.ptr(gamma),
+            hb.ptr(beta), hb.ptr(mean), hb.ptr(rstd), hb.ptr(_bn_partial(c, n, x.device)), hb.i32(c), hb.i32(n), hb.i32(act),
+            hb.ptr(dx), hb.ptr(dr), hb.ptr(dgamma), hb.ptr(dbeta))
+    return dx, dr, dgamma, dbeta
+
+
 def patch_matrix_supported(x: torch.Tensor, kh: int, kw: int, ph: int, pw: int) -> bool:
     """True when :func:`patch_matrix_cm` can build the patch matrix of ``x`` ``[C, B, H, W]``."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and available()):
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() == 4 and available()):
         return False
     if (kh, kw) not in ((3, 3), (5, 5)) or not (0 <= ph < kh and 0 <= pw < kw):
         return False
@@ -161,21 +214,21 @@ def patch_matrix_supported(x: torch.Tensor, kh: int, kw: int, ph: int, pw: int) 
     oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
     if oh <= 0 or ow <= 0 or (b * oh * ow) % 8 != 0 or c > 65535 or c * b * h * w >= 2**31 or b * oh * ow >= 2**31:
         return False
-    return (2048 // (oh * ow) + 2) * h * w * 2 <= 64 * 1024  # boards one workgroup stages in LDS
+    return (2048 // (oh * ow) + 2) * h * w * x.element_size() <= 64 * 1024  # boards one workgroup stages in LDS
 
 
 def patch_matrix_cm(x: torch.Tensor, kh: int, kw: int, ph: int, pw: int) -> torch.Tensor:
-    """Stride-1 im2col of a channel-major activation ``[C, B, H, W]`` (bf16) -> ``[C*kh*kw, B*oh*ow]`` in one launch.
+    """Stride-1 im2col of a channel-major activation ``[C, B, H, W]`` (bf16 or f32) -> ``[C*kh*kw, B*oh*ow]`` in one launch.
 
     Row order ``(c, ky, kx)``, column order ``(b, oy, ox)``: the B operand of the learner's convolution GEMMs
     (``patch_matrix_kernel`` in csrc/hip/learner_kernels.hip).
     """
     if not patch_matrix_supported(x, kh, kw, ph, pw):
-        raise ValueError("patch_matrix_cm: unsupported input (needs a CUDA bf16 [C, B, H, W] tensor, 3x3 or 5x5 taps)")
+        raise ValueError("patch_matrix_cm: unsupported input (needs a CUDA bf16 / f32 [C, B, H, W] tensor, 3x3 or 5x5 taps)")
     x = x.contiguous()
     c, b, h, w = x.shape
     oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-    cols = torch.empty(c * kh * kw, b * oh * ow, dtype=torch.bfloat16, device=x.device)
-    hb.call("atri_patch_matrix", hb.ptr(x), hb.ptr(cols), hb.i32(c), hb.i32(b), hb.i32(h), hb.i32(w), hb.i32(kh), hb.i32(kw),
+    cols = torch.empty(c * kh * kw, b * oh * ow, dtype=x.dtype, device=x.device)
+    hb.call("atri_patch_matrix", hb.ptr(x), hb.ptr(cols), hb.i32(1 if x.dtype == torch.bfloat16 else 0), hb.i32(c), hb.i32(b), hb.i32(h), hb.i32(w), hb.i32(kh), hb.i32(kw),
             hb.i32(ph), hb.i32(pw))
     return cols

@@ -248,14 +248,15 @@ def test_layer_norm_kernels_match_torch(rows, d, dtype):
 
 @pytest.mark.parametrize("c,b,h,w,k,p", [(128, 256, 8, 15, 3, 1), (1, 256, 8, 15, 3, 1), (32, 64, 8, 15, 3, 0), (16, 8, 12, 21, 5, 2),
                                          (64, 32, 5, 9, 3, 2)])
-def test_patch_matrix_kernel_matches_torch_gather(c, b, h, w, k, p):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_patch_matrix_kernel_matches_torch_gather(c, b, h, w, k, p, dtype):
     """patch_matrix_kernel (channel-major im2col, one launch) against strided-view gathering in PyTorch: exact copies."""
     from alphatriangle_amd.models.model import _patch_matrix
     from alphatriangle_amd.ops import hip_learner
 
     torch.manual_seed(c + b)
     dev = torch.device("cuda")
-    x = torch.randn(c, b, h, w, device=dev).to(torch.bfloat16)
+    x = torch.randn(c, b, h, w, device=dev).to(dtype)
     assert hip_learner.patch_matrix_supported(x, k, k, p, p)
     cols = hip_learner.patch_matrix_cm(x, k, k, p, p)
     ref = _patch_matrix(x.permute(1, 0, 2, 3).contiguous(), k, k, p, p)
@@ -312,3 +313,92 @@ def test_channel_major_conv_body_matches_nchw_path(preset):
     for (name, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         if "running" in name:
             assert torch.allclose(ba.float(), bb.float(), rtol=2e-2, atol=2e-3), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["ReLU", "GELU", "Identity"])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_fused_batchnorm_act_kernels_match_torch(dtype, act, with_residual):
+    """Channel-major BatchNorm (+ skip) (+ activation), forward and backward, against torch in fp32."""
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(17)
+    dev = torch.device("cuda")
+    c, b, h, w = 96, 64, 8, 15
+    x = (torch.randn(c, b, h, w, device=dev) * 1.7 + 3.0).to(dtype)  # a large mean: the shifted one-pass variance has to cope
+    r = torch.randn(c, b, h, w, device=dev).to(dtype) if with_residual else None
+    gy = torch.randn(c, b, h, w, device=dev).to(dtype)
+    bn = torch.nn.BatchNorm2d(c).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+    ref_bn = torch.nn.BatchNorm2d(c).to(dev).train()
+    ref_bn.load_state_dict(bn.state_dict())
+    act_id = hip_learner.ACT_IDS[act]
+    y, mean, rstd = hip_learner.bn_act_cm_forward(x, r, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, bn.running_mean,
+                                                  bn.running_var, bn.num_batches_tracked, act_id)
+    dx, dr, dg, db = hip_learner.bn_act_cm_backward(x, r, gy, bn.weight.detach(), bn.bias.detach(), mean, rstd, act_id)
+    # reference: NCHW fp32
+    xr = x.float().permute(1, 0, 2, 3).contiguous().requires_grad_(True)
+    rr = r.float().permute(1, 0, 2, 3).contiguous().requires_grad_(True) if r is not None else None
+    z = ref_bn(xr) + (rr if rr is not None else 0)
+    yr = getattr(torch.nn, act)()(z)
+    grads = torch.autograd.grad(yr, [xr, ref_bn.weight, ref_bn.bias] + ([rr] if rr is not None else []), gy.float().permute(1, 0, 2, 3))
+    torch.cuda.synchronize()
+    tol = 3e-2 if dtype == torch.bfloat16 else 2e-4
+
+    def close(a, ref, what):
+        err = (a.float() - ref).abs().max().item()
+        assert err < tol * max(1.0, ref.abs().max().item()), (what, err)
+
+    close(y.permute(1, 0, 2, 3), yr, "y")
+    close(dx.permute(1, 0, 2, 3), grads[0], "dx")
+    close(dg, grads[1], "dgamma") if dtype == torch.float32 else None
+    close(db, grads[2], "dbeta") if dtype == torch.float32 else None
+    if rr is not None:
+        close(dr.permute(1, 0, 2, 3), grads[3], "dr")
+    assert torch.allclose(bn.running_mean, ref_bn.running_mean, rtol=1e-3, atol=2e-3 if dtype == torch.bfloat16 else 1e-5)
+    assert torch.allclose(bn.running_var, ref_bn.running_var, rtol=2e-2 if dtype == torch.bfloat16 else 1e-4, atol=1e-4)
+    assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("preset", ["default", "cnn"])
+def test_fp32_learner_fast_path_matches_stock_modules(preset):
+    """fp32 (no autocast): channel-major body + fused BatchNorm kernels against the plain NCHW module path - same outputs,
+    gradients and running statistics to fp32 rounding."""
+    import copy
+
+    from alphatriangle_amd.models.model import AlphaTriangleNet
+
+    torch.manual_seed(23)
+    dev = torch.device("cuda")
+    env = EnvConfig()
+    mc = ModelConfig() if preset == "default" else ModelConfig.cnn_only()
+    net_a = AlphaTriangleNet(mc, env).to(dev).train()
+    for m in net_a.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    net_b = copy.deepcopy(net_a)
+    net_b.channel_major = False
+    B = 64
+    grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    assert net_a._cm_plan_ok(grid) and not net_b._cm_plan_ok(grid)
+    res = []
+    for net in (net_a, net_b):
+        pl, vl = net(grid, other)
+        (pl.square().mean() + vl.square().mean()).backward()
+        res.append((pl.detach(), vl.detach(), {n: p.grad for n, p in net.named_parameters()}))
+    torch.cuda.synchronize()
+    assert (res[0][0] - res[1][0]).abs().max().item() < 2e-4 and (res[0][1] - res[1][1]).abs().max().item() < 2e-4
+    top = max(g.abs().max().item() for g in res[1][2].values())
+    for name, g in res[1][2].items():
+        scale = max(g.abs().max().item(), 1e-4 * top)  # gradients that are zero up to rounding are compared on the global scale
+        assert (res[0][2][name] - g).abs().max().item() / scale < 5e-3, name
+    for (name, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        if "running" in name:
+            assert torch.allclose(ba, bb, rtol=1e-3, atol=1e-5), name
+        if "num_batches_tracked" in name:
+            assert int(ba) == int(bb), name  # the in-kernel counter bump equals the module's own
