@@ -344,6 +344,32 @@ class FastLayerNorm(nn.LayerNorm):
         return norm  # type: ignore[return-value]
 
 
+class _FusedAttention(torch.autograd.Function):
+    """Multi-head self-attention over packed ``qkv [L, B, 3D]`` rows through ``ops.hip_learner.attention_*``.
+
+    One launch forward and one backward per layer; scores, probabilities and the dropout mask never reach memory
+    (the backward recomputes them from ``qkv``, one log-sum-exp per query and the dropout seed).
+    """
+
+    @staticmethod
+    def forward(ctx, qkv: torch.Tensor, heads: int, p_drop: float) -> torch.Tensor:  # noqa: ANN001
+        from ..ops import hip_learner
+
+        qkv = qkv.contiguous()
+        out, lse, seed = hip_learner.attention_forward(qkv, heads, p_drop)
+        ctx.save_for_backward(qkv, lse, seed if seed is not None else lse.new_empty(0))
+        ctx.heads, ctx.p_drop = heads, p_drop
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        qkv, lse, seed = ctx.saved_tensors
+        dqkv = hip_learner.attention_backward(qkv, grad_out, lse, seed if ctx.p_drop > 0 else None, ctx.heads, ctx.p_drop)
+        return dqkv, None, None
+
+
 class EncoderLayer(nn.TransformerEncoderLayer):
     """``nn.TransformerEncoderLayer`` (same sub-modules, same ``state_dict`` keys) with a learner fast path.
 
@@ -378,18 +404,28 @@ class EncoderLayer(nn.TransformerEncoderLayer):
         heads = attn.num_heads
         y = self.norm1(src)
         qkv = _linear_rows(y, attn.in_proj_weight, attn.in_proj_bias)  # [L, B, 3D]
-        q, k, v = (t.reshape(seq, batch, heads, dim // heads).permute(1, 2, 0, 3) for t in qkv.chunk(3, dim=-1))
-        # Written-out attention (two batched GEMMs around a softmax) instead of the flash kernel: with 120 tokens the
-        # score matrix is small, and the flash backward zero-fills its accumulators through memset nodes, which
-        # keeps the learner step out of a replayable HIP graph.
-        scores = (q * (dim // heads) ** -0.5) @ k.transpose(-2, -1)  # [B, H, L, L]
-        with torch.autocast(device_type=src.device.type, enabled=False):
-            probs = torch.softmax(scores, dim=-1)  # bf16 in / bf16 out under autocast, fp32 accumulation inside
-        probs = torch.nn.functional.dropout(probs, attn.dropout, self.training)
-        ctx = (probs @ v).permute(2, 0, 1, 3).reshape(seq, batch, dim)
+        ctx = self._attention(qkv, seq, batch, dim, heads)
         x = src + self.dropout1(_linear_rows(ctx, attn.out_proj.weight, attn.out_proj.bias))
         hidden = self.dropout(self.activation(_linear_rows(self.norm2(x), self.linear1.weight, self.linear1.bias)))
         return x + self.dropout2(_linear_rows(hidden, self.linear2.weight, self.linear2.bias))
+
+
+    fused_attention = True  # one-launch HIP attention where it applies; False keeps the batched-GEMM formulation
+
+    def _attention(self, qkv: torch.Tensor, seq: int, batch: int, dim: int, heads: int) -> torch.Tensor:
+        from ..ops import hip_learner
+
+        attn = self.self_attn
+        if self.fused_attention and dim == 32 * heads and hip_learner.attention_supported(qkv, heads):
+            return _FusedAttention.apply(qkv, heads, float(attn.dropout) if self.training else 0.0)
+        q, k, v = (t.reshape(seq, batch, heads, dim // heads).permute(1, 2, 0, 3) for t in qkv.chunk(3, dim=-1))
+        # Written-out attention (two batched GEMMs around a softmax) instead of the flash kernel: the flash backward
+        # zero-fills its accumulators through memset nodes, which keeps the learner step out of a replayable HIP graph.
+        scores = (q * (dim // heads) ** -0.5) @ k.transpose(-2, -1)  # [B, H, L, L]
+        with torch.autocast(device_type=qkv.device.type, enabled=False):
+            probs = torch.softmax(scores, dim=-1)  # bf16 in / bf16 out under autocast, fp32 accumulation inside
+        probs = torch.nn.functional.dropout(probs, attn.dropout, self.training)
+        return (probs @ v).permute(2, 0, 1, 3).reshape(seq, batch, dim)
 
 
 def conv_block(

@@ -204,6 +204,48 @@ def bn_act_cm_backward(x: torch.Tensor, residual: torch.Tensor | None, dy: torch
     return dx, dr, dgamma, dbeta
 
 
+# ---------------------------------------------------------------- fused multi-head self-attention (32-wide heads)
+def attention_supported(qkv: torch.Tensor, heads: int) -> bool:
+    """True when :func:`attention_forward` handles packed ``qkv [L, B, 3 * 32 * heads]`` (bf16 or f32, up to 256 tokens)."""
+    if not (qkv.is_cuda and qkv.dim() == 3 and qkv.dtype in (torch.bfloat16, torch.float32) and available()):
+        return False
+    seq, batch, width = qkv.shape
+    pitch = 256 if seq > 128 else 128
+    return bool(width == 96 * heads and 1 <= seq <= 256 and batch * heads * pitch * pitch < 2**32)
+
+
+def _lse_pitch(seq: int) -> int:
+    return 256 if seq > 128 else 128
+
+
+def attention_forward(qkv: torch.Tensor, heads: int, p_drop: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None]:
+    """``dropout(softmax(Q K^T / sqrt(32))) V`` per (sample, head) in one launch (``attn_fwd_kernel``).
+
+    Returns ``(ctx [L, B, 32 * heads], lse, seed)``: ``lse`` (log2-domain log-sum-exp per query) and ``seed`` (the dropout
+    seed, drawn from torch's generator so that ``torch.manual_seed`` governs it and a captured step draws a new one on
+    every replay) are what :func:`attention_backward` needs next to ``qkv``.
+    """
+    qkv = qkv.contiguous()
+    seq, batch, width = qkv.shape
+    ctx = torch.empty(seq, batch, width // 3, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(batch * heads, _lse_pitch(seq), dtype=torch.float32, device=qkv.device)
+    seed = torch.randint(0, 2**62, (1,), dtype=torch.int64, device=qkv.device) if p_drop > 0 else None
+    hb.call("atri_attn_fwd", hb.ptr(qkv), hb.i32(1 if qkv.dtype == torch.bfloat16 else 0), hb.ptr(ctx), hb.ptr(lse), hb.ptr(seed),
+            hb.i32(seq), hb.i32(batch), hb.i32(heads), hb.f32(p_drop))
+    return ctx, lse, seed
+
+
+def attention_backward(qkv: torch.Tensor, dctx: torch.Tensor, lse: torch.Tensor, seed: torch.Tensor | None, heads: int,
+                       p_drop: float) -> torch.Tensor:
+    """Gradient of the packed ``qkv`` rows for :func:`attention_forward` in one launch (``attn_bwd_kernel``)."""
+    seq, batch, _ = qkv.shape
+    dctx = dctx.to(qkv.dtype).contiguous()
+    dqkv = torch.empty_like(qkv)
+    hb.call("atri_attn_bwd", hb.ptr(qkv), hb.ptr(dctx), hb.i32(1 if qkv.dtype == torch.bfloat16 else 0), hb.ptr(dqkv), hb.ptr(lse),
+            hb.ptr(seed), hb.i32(seq), hb.i32(batch), hb.i32(heads), hb.f32(p_drop))
+    return dqkv
+
+
 def patch_matrix_supported(x: torch.Tensor, kh: int, kw: int, ph: int, pw: int) -> bool:
     """True when :func:`patch_matrix_cm` can build the patch matrix of ``x`` ``[C, B, H, W]``."""
     if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() == 4 and available()):

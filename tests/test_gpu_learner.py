@@ -368,7 +368,7 @@ def test_fp32_learner_fast_path_matches_stock_modules(preset):
     gradients and running statistics to fp32 rounding."""
     import copy
 
-    from alphatriangle_amd.models.model import AlphaTriangleNet
+    from alphatriangle_amd.models.model import AlphaTriangleNet, EncoderLayer
 
     torch.manual_seed(23)
     dev = torch.device("cuda")
@@ -382,6 +382,9 @@ def test_fp32_learner_fast_path_matches_stock_modules(preset):
             m.dropout = 0.0
     net_b = copy.deepcopy(net_a)
     net_b.channel_major = False
+    for m in net_b.modules():
+        if isinstance(m, EncoderLayer):
+            m.fused_attention = False  # batched-GEMM attention on the comparison side
     B = 64
     grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
     other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
@@ -402,3 +405,90 @@ def test_fp32_learner_fast_path_matches_stock_modules(preset):
             assert torch.allclose(ba, bb, rtol=1e-3, atol=1e-5), name
         if "num_batches_tracked" in name:
             assert int(ba) == int(bb), name  # the in-kernel counter bump equals the module's own
+
+
+def _dropout_keep_mask(seed: int, bh: int, seq: int, p: float, device) -> torch.Tensor:
+    """Host re-statement of ``drop_hash`` in csrc/hip/learner_attn_kernels.hip: keep[bh, query, key]."""
+    lp = 256 if seq > 128 else 128
+    m32 = 0xFFFFFFFF
+    s0, s1 = seed & m32, (seed >> 32) & m32
+    thresh = int(float(np.float32(p)) * 4294967296.0)
+    i = torch.arange(bh, device=device, dtype=torch.int64).view(-1, 1, 1)
+    q = torch.arange(seq, device=device, dtype=torch.int64).view(1, -1, 1)
+    k = torch.arange(seq, device=device, dtype=torch.int64).view(1, 1, -1)
+    x = (((i * lp + q) * lp + k) & m32) * 0x9E3779B1 + s0 & m32
+    x = ((x ^ (x >> 16)) * 0x85EBCA6B) & m32
+    x = ((x ^ (x >> 13)) * 0xC2B2AE35) & m32
+    x = ((x ^ (x >> 16)) + s1) & m32
+    x = ((x ^ (x >> 15)) * 0x2C1B3C6D) & m32
+    x = x ^ (x >> 12)
+    return x >= thresh
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("seq,batch,heads,p", [(120, 16, 4, 0.0), (120, 16, 4, 0.1), (30, 5, 2, 0.25), (252, 6, 4, 0.1), (129, 3, 1, 0.0)])
+def test_fused_attention_kernels_match_torch(dtype, seq, batch, heads, p):
+    """One-launch attention forward / backward against an fp64 PyTorch statement of the same arithmetic (same dropout mask)."""
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(31)
+    dev = torch.device("cuda")
+    dim = 32 * heads
+    qkv = (torch.randn(seq, batch, 3 * dim, device=dev) * 1.5).to(dtype)
+    w = torch.randn(seq, batch, dim, device=dev).to(dtype)
+    assert hip_learner.attention_supported(qkv, heads)
+    ctx, lse, seed = hip_learner.attention_forward(qkv, heads, p)
+    dqkv = hip_learner.attention_backward(qkv, w, lse, seed, heads, p)
+    torch.cuda.synchronize()
+
+    ref_in = qkv.double().requires_grad_(True)
+    q, k, v = (t.reshape(seq, batch, heads, 32).permute(1, 2, 0, 3) for t in ref_in.chunk(3, dim=-1))
+    probs = torch.softmax(q @ k.transpose(-2, -1) / 32**0.5, dim=-1)
+    if p > 0:
+        keep = _dropout_keep_mask(int(seed.item()), batch * heads, seq, p, dev).view(batch, heads, seq, seq)
+        rate = 1.0 - keep.double().mean().item()
+        assert abs(rate - p) < 0.01, f"drop rate {rate} for p = {p}"
+        probs = probs * keep / (1.0 - float(np.float32(p)))
+    ref = (probs @ v).permute(2, 0, 1, 3).reshape(seq, batch, dim)
+    (ref * w.double()).sum().backward()
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    err_f = (ctx.double() - ref).abs().max().item() / ref.abs().max().item()
+    err_b = (dqkv.double() - ref_in.grad).abs().max().item() / ref_in.grad.abs().max().item()
+    print(f"[{dtype}, L={seq}, p={p}] forward {err_f:.2e}, backward {err_b:.2e}")
+    assert err_f < tol and err_b < tol
+    lse_ref = torch.logsumexp(q @ k.transpose(-2, -1) / 32**0.5, dim=-1) / np.log(2.0)
+    assert (lse.view(batch, heads, -1)[:, :, :seq].double() - lse_ref).abs().max().item() < (1e-4 if dtype == torch.float32 else 5e-2)
+
+
+def test_fused_attention_draws_a_new_mask_on_every_graph_replay():
+    """Captured forward + backward replayed three times: every replay equals an eager run with the seed it drew."""
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(37)
+    dev = torch.device("cuda")
+    seq, batch, heads, p = 120, 8, 4, 0.1
+    qkv = torch.randn(seq, batch, 96 * heads, device=dev)
+    w = torch.randn(seq, batch, 32 * heads, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hip_learner.attention_forward(qkv, heads, p)  # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ctx, lse, seed = hip_learner.attention_forward(qkv, heads, p)
+        dqkv = hip_learner.attention_backward(qkv, w, lse, seed, heads, p)
+    seeds = []
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        seeds.append(int(seed.item()))
+        eager_ctx = torch.empty_like(ctx)
+        eager_lse = torch.empty_like(lse)
+        hip_learner.hb.call("atri_attn_fwd", hip_learner.hb.ptr(qkv), hip_learner.hb.i32(0), hip_learner.hb.ptr(eager_ctx),
+                            hip_learner.hb.ptr(eager_lse), hip_learner.hb.ptr(seed), hip_learner.hb.i32(seq), hip_learner.hb.i32(batch),
+                            hip_learner.hb.i32(heads), hip_learner.hb.f32(p))
+        eager_dqkv = hip_learner.attention_backward(qkv, w, eager_lse, seed, heads, p)
+        torch.cuda.synchronize()
+        assert torch.equal(eager_ctx, ctx) and torch.equal(eager_dqkv, dqkv)
+    assert len(set(seeds)) == 3, "every replay has to draw its own dropout seed"
