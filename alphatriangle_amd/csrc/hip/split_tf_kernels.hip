@@ -1,4 +1,4 @@
-// fp32-grade pre-LN Transformer encoder layer in one launch, one 8-wave workgroup per sample (up to 128 tokens,
+// fp32-grade pre-LN Transformer encoder layer in one launch, 8-wave workgroups that take one sample at a time (up to 128 tokens,
 // d_model 128, 4 heads of 32): nn.TransformerEncoderLayer(norm_first=True) as instantiated at
 // alphatriangle/nn/model.py:189-196, LayerNorm affine parts folded into the following projections by the host.
 //
@@ -8,14 +8,20 @@
 //
 // Work split: wave w = (channel block / head h = w & 3, token half = w >> 2); every GEMM gives a wave 64 tokens x
 // 32 channels.  LDS holds two 72 KB regions:
-//   A: (hi, lo) planes of the GEMM input tile - LayerNorm1(x), later the V^T exchange image, the attention output,
-//      LayerNorm2(y);
-//   B: the K operand image of all heads (read at use by the attention loop), later y in fp32 for LayerNorm2, later
-//      the (hi, lo) planes of the FFN hidden tile.
-// Q stays in registers (a wave attends for its own 64 queries); K and V^T of a head are produced half by each wave of
-// the head's pair and exchanged through lane-linear operand images (producer and consumer lanes hold identical
-// fragments, so the exchange is conflict free); V^T then lives in registers, K is read from LDS at use.  The residual
-// stream y stays in fp32 registers between the attention half and the end of the FFN half.
+//   A: (hi, lo) planes of the GEMM input tile - LayerNorm1(x), later the attention output, later LayerNorm2(y);
+//   B: the K operand image of all heads (read at use by the attention loop), later the per-wave LayerNorm2 statistics,
+//      later the (hi, lo) planes of the FFN hidden tile.
+// Q and V^T stay in registers: a wave attends for its own 64 queries and computes V^T of its head for all 128 keys
+// itself (the second half is redundant work on an otherwise idle matrix pipe and saves an exchange with two
+// barriers); K of a head is produced half by each wave of the head's pair and read from a lane-linear operand image.
+// The residual stream y stays in fp32 registers from the output projection to the end of the layer; LayerNorm2 works
+// on those registers (per-wave mean / M2 over its 32 channels, combined across the four channel blocks through 4 KB
+// of LDS).
+//
+// Latency hiding, one workgroup per CU: weights sit in one 64-register ring (the slice a GEMM step has just used is
+// refilled with the next GEMM's slice), GEMM input fragments are double buffered, the scores of the next query tile
+// are issued before the softmax of the current one, and the workgroup is persistent (one per CU, samples strided by the
+// grid): the next sample's input rows are requested before the last GEMM of the current sample and normalised after it.
 #include "common.hpp"
 
 using namespace atrihip;
@@ -34,60 +40,80 @@ struct SplitEncArgs {
   long long lo_qkv, lo_o, lo_1, lo_2;
   int B, HW, F, act;
   float eps1, eps2;
+  long long* phase_clock;     // diagnostics: workgroup `phase_block` stores the shader clock at its phase boundaries
+  int phase_block;
 };
+
+#define ATRI_PHASE(i)                                                                                               \
+  do {                                                                                                              \
+    if (a.phase_clock != nullptr && (int)blockIdx.x == a.phase_block && iter == 1 && tid == 0) a.phase_clock[i] = clock64(); \
+  } while (0)
 
 namespace {
 constexpr int kDs = 128;
 constexpr int kStrideS = 288;                  // bytes per token row of a bf16 plane
 constexpr int kPlane = 128 * kStrideS;         // 36,864
 constexpr int kRegion = 2 * kPlane;            // 73,728
-constexpr int kYPitch = 132;                   // floats per token row of the fp32 y tile
 
 typedef __attribute__((ext_vector_type(4))) short short4v;
 
 struct WSplit {
   short8 h[4][2], l[4][2];
 };
-__device__ __forceinline__ void load_wsplit(WSplit& w, const unsigned short* __restrict__ base, long long lo_off, size_t frag) {
-  const short8* ph = reinterpret_cast<const short8*>(base) + frag;
-  const short8* pl = reinterpret_cast<const short8*>(base + lo_off) + frag;
+struct WRef {  // this lane's fragment of K-step 0 in the hi and lo streams; K-steps are 512 fragments apart
+  const short8* h;
+  const short8* l;
+};
+__device__ __forceinline__ WRef wref(const unsigned short* base, long long lo_off, size_t frag) {
+  return {reinterpret_cast<const short8*>(base) + frag, reinterpret_cast<const short8*>(base + lo_off) + frag};
+}
+__device__ __forceinline__ void load_wslice(WSplit& w, int kc, const WRef& r) {
+  w.h[kc][0] = r.h[kc * 512];
+  w.h[kc][1] = r.h[kc * 512 + 64];
+  w.l[kc][0] = r.l[kc * 512];
+  w.l[kc][1] = r.l[kc * 512 + 64];
+}
+__device__ __forceinline__ void load_wsplit(WSplit& w, const WRef& r) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int kc = 0; kc < 4; ++kc) {
-    w.h[kc][0] = ph[kc * 512];
-    w.h[kc][1] = ph[kc * 512 + 64];
-    w.l[kc][0] = pl[kc * 512];
-    w.l[kc][1] = pl[kc * 512 + 64];
-  }
+  for (int kc = 0; kc < 4; ++kc) load_wslice(w, kc, r);
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc[t][n] (+)= W x over K = 128 for this wave's four token tiles (tile0 .. tile0 + 3) of the (hi, lo) planes at `tile`.
+__device__ __forceinline__ void load_x(short8 (&xh)[4], short8 (&xl)[4], const unsigned char* base, int kc) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    xh[t] = *reinterpret_cast<const short8*>(base + t * 16 * kStrideS + kc * 64);
+    xl[t] = *reinterpret_cast<const short8*>(base + kPlane + t * 16 * kStrideS + kc * 64);
+  }
+}
+
+// acc[t][n] (+)= W x over K = 128 for four token tiles (tile0 .. tile0 + 3) of the (hi, lo) planes at `tile`.
 // SWAP = false: weights are the MFMA A operand (lane ends with 8 consecutive output channels of token l15);
 // SWAP = true : the tile is the A operand (lane ends with 4 consecutive tokens of one output channel).
-template <bool SWAP>
-__device__ __forceinline__ void gemm_split_k128(float4v (&acc)[4][2], const WSplit& w, const unsigned char* tile, int tile0, int l15, int q4) {
+// NEXT: each K-step's weight registers are refilled from `next` as soon as its MFMAs are issued.
+template <bool SWAP, bool NEXT>
+__device__ __forceinline__ void gemm_split_k128(float4v (&acc)[4][2], WSplit& w, const unsigned char* tile, int tile0, int l15, int q4,
+                                                const WRef& next) {
   const unsigned char* base = tile + (tile0 * 16 + l15) * kStrideS + q4 * 16;
+  short8 xh[2][4], xl[2][4];
+  load_x(xh[0], xl[0], base, 0);
 #pragma unroll
   for (int kc = 0; kc < 4; ++kc) {
-    short8 xh[4], xl[4];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      xh[t] = *reinterpret_cast<const short8*>(base + t * 16 * kStrideS + kc * 64);
-      xl[t] = *reinterpret_cast<const short8*>(base + kPlane + t * 16 * kStrideS + kc * 64);
-    }
+    if (kc < 3) load_x(xh[(kc + 1) & 1], xl[(kc + 1) & 1], base, kc + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (SWAP) {
-        acc[t][0] = mfma_split(xh[t], xl[t], w.h[kc][0], w.l[kc][0], acc[t][0]);
-        acc[t][1] = mfma_split(xh[t], xl[t], w.h[kc][1], w.l[kc][1], acc[t][1]);
+        acc[t][0] = mfma_split(xh[kc & 1][t], xl[kc & 1][t], w.h[kc][0], w.l[kc][0], acc[t][0]);
+        acc[t][1] = mfma_split(xh[kc & 1][t], xl[kc & 1][t], w.h[kc][1], w.l[kc][1], acc[t][1]);
       } else {
-        acc[t][0] = mfma_split(w.h[kc][0], w.l[kc][0], xh[t], xl[t], acc[t][0]);
-        acc[t][1] = mfma_split(w.h[kc][1], w.l[kc][1], xh[t], xl[t], acc[t][1]);
+        acc[t][0] = mfma_split(w.h[kc][0], w.l[kc][0], xh[kc & 1][t], xl[kc & 1][t], acc[t][0]);
+        acc[t][1] = mfma_split(w.h[kc][1], w.l[kc][1], xh[kc & 1][t], xl[kc & 1][t], acc[t][1]);
       }
     }
+    if (NEXT) load_wslice(w, kc, next);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -96,41 +122,53 @@ __device__ __forceinline__ void split8(const float4v& a, const float4v& b, short
   split_bf16x8(f, hi, lo);
 }
 
-// LayerNorm (no affine part) of 64 rows per pass from fp32 rows at `src` (row pitch `pitch` floats), 8 lanes per row,
-// result split into the two planes of `dst`.  Rows >= nrows become zero rows.
-template <bool FROM_LDS>
-__device__ __forceinline__ void layernorm_to_planes(const float* src, int pitch, unsigned char* dst, int nrows, float eps, int tid) {
+// LayerNorm (no affine part) of a sample's rows from fp32 global memory in two steps, 8 lanes per row and two rows per
+// thread: ln_load issues every load, ln_finish reduces, normalises and splits the result into the two planes of `dst`
+// (rows >= nrows become zero rows).  Whatever runs between the two steps hides the memory latency.
+// Sum over the 8 lanes that share (lane >> 3): two quad permutes and a half-row mirror, all DPP (no LDS round trip).
+__device__ __forceinline__ float sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return v;
+}
+
+struct LnRows {
+  float4 v[2][4];
+};
+__device__ __forceinline__ void ln_load(LnRows& x, const float* src, int nrows, int tid) {
   const int l8 = tid & 7;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int row = pass * 64 + (tid >> 3);
-    const bool live = row < nrows;
-    float4 v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live) v[j] = *reinterpret_cast<const float4*>(src + (size_t)row * pitch + (j * 8 + l8) * 4);
+      x.v[pass][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nrows) x.v[pass][j] = *reinterpret_cast<const float4*>(src + (size_t)row * kDs + (j * 8 + l8) * 4);
     }
+  }
+}
+__device__ __forceinline__ void ln_finish(LnRows& x, unsigned char* dst, float eps, int tid) {
+  const int l8 = tid & 7;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int row = pass * 64 + (tid >> 3);
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    const float mean = s * (1.0f / kDs);
+    for (int j = 0; j < 4; ++j) s += (x.v[pass][j].x + x.v[pass][j].y) + (x.v[pass][j].z + x.v[pass][j].w);
+    const float mean = sum8(s) * (1.0f / kDs);
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
-      ss += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+      float4& q = x.v[pass][j];
+      q.x -= mean; q.y -= mean; q.z -= mean; q.w -= mean;
+      ss += (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
     }
-    ss += __shfl_xor(ss, 1, 64);
-    ss += __shfl_xor(ss, 2, 64);
-    ss += __shfl_xor(ss, 4, 64);
-    const float rstd = rsqrtf(ss * (1.0f / kDs) + eps);
+    const float rstd = rsqrtf(sum8(ss) * (1.0f / kDs) + eps);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float o0 = v[j].x * rstd, o1 = v[j].y * rstd, o2 = v[j].z * rstd, o3 = v[j].w * rstd;
+      const float4& q = x.v[pass][j];
+      const float o0 = q.x * rstd, o1 = q.y * rstd, o2 = q.z * rstd, o3 = q.w * rstd;
       const unsigned h0 = pack_bf16x2(o0, o1), h1 = pack_bf16x2(o2, o3);
       const float r0 = o0 - bf16_to_float((unsigned short)(h0 & 0xFFFF)), r1 = o1 - bf16_to_float((unsigned short)(h0 >> 16));
       const float r2 = o2 - bf16_to_float((unsigned short)(h1 & 0xFFFF)), r3 = o3 - bf16_to_float((unsigned short)(h1 >> 16));
@@ -140,6 +178,84 @@ __device__ __forceinline__ void layernorm_to_planes(const float* src, int pitch,
     }
   }
 }
+
+// Scores of query tile t of this wave against all 128 keys of its head, key-major: st[kt][j] = score of key
+// 16 kt + 4 q4 + j for query l15 of the tile, in log2 units.  Padded keys get -1e30 (probability 0): branch-free, and
+// with TAIL (more than 112 tokens) only the last key tile can hold padding.
+template <bool TAIL>
+__device__ __forceinline__ void attn_scores(float4v (&st)[8], const short8* kimg, const short8& qh, const short8& ql, int HW, int q4) {
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) {
+    const short8 kh = kimg[(size_t)kt * 128], kl = kimg[(size_t)kt * 128 + 64];
+    st[kt] = mfma_split(kh, kl, qh, ql, (float4v){0.f, 0.f, 0.f, 0.f});
+  }
+#pragma unroll
+  for (int kt = TAIL ? 7 : 0; kt < 8; ++kt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st[kt][j] = kt * 16 + q4 * 4 + j >= HW ? -1e30f : st[kt][j];
+}
+
+// Attention of head cb for this wave's four query tiles; the output rows go to the planes at A.  SAFE subtracts the
+// row maxima before exp2; the other form leaves range checking of the denominators to the caller (returned: true when
+// a lane saw one out of range).  The max-free form also starts the loads of the weights `after`.  Softmax is shift invariant and the (hi, lo) split keeps fp32's exponent range, so the
+// max-free form is exact as long as no denominator overflows or vanishes.
+template <bool SAFE, bool TAIL>
+__device__ __forceinline__ bool attention_tiles(const short8 (&qh)[4], const short8 (&ql)[4], const short8 (&vth)[4][2],
+                                                const short8 (&vtl)[4][2], const short8* kimg, unsigned char* A, int HW, int tile0,
+                                                int cb, int q4, int l15, WSplit& w, const WRef& after) {
+  bool suspect = false;
+  float4v st[2][8];
+  attn_scores<TAIL>(st[0], kimg, qh[0], ql[0], HW, q4);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    float4v(&s)[8] = st[t & 1];
+    if (t < 3) attn_scores<TAIL>(st[(t + 1) & 1], kimg, qh[t + 1], ql[t + 1], HW, q4);
+    if (!SAFE && t == 3) {  // the weights of the GEMM after attention fly during the last tile (the ring is idle until then)
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) load_wslice(w, kc, after);
+    }
+    float m = 0.f;
+    if (SAFE) {
+      m = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = fmaxf(m, s[kt][j]);
+      m = quad_row_max(m);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[kt][j] = __builtin_amdgcn_exp2f(SAFE ? s[kt][j] - m : s[kt][j]);
+        sum += s[kt][j];
+      }
+    sum = quad_row_sum(sum);
+    if (!SAFE) suspect |= !(sum > 7.9e-31f && sum < 1.2e30f);  // outside [2^-100, 2^100] or NaN
+    float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      short8 ph, pl;
+      split8(s[2 * kb], s[2 * kb + 1], ph, pl);
+      o0 = mfma_split(vth[kb][0], vtl[kb][0], ph, pl, o0);
+      o1 = mfma_split(vth[kb][1], vtl[kb][1], ph, pl, o1);
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o0[j] *= inv;
+      o1[j] *= inv;
+    }
+    // lane holds channels cb*32 + q4*8 .. +7 of query (tile0 + t)*16 + l15
+    short8 oh, ol;
+    split8(o0, o1, oh, ol);
+    unsigned char* p = A + ((tile0 + t) * 16 + l15) * kStrideS + cb * 64 + q4 * 16;
+    *reinterpret_cast<short8*>(p) = oh;
+    *reinterpret_cast<short8*>(p + kPlane) = ol;
+  }
+  return suspect;
+}
 }  // namespace
 
 template <int HALVES>
@@ -147,19 +263,38 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* A = smem;
   unsigned char* Bq = smem + kRegion;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HW = a.HW;
+  const WRef none{nullptr, nullptr};
+
+  // The workgroup is persistent: it walks samples blockIdx.x, blockIdx.x + gridDim.x, ...  The input rows of the next
+  // sample are requested before the last GEMM of the current one and normalised right after it, so that the only
+  // exposed memory latency is that of the first sample.
+  WSplit w;
+  {
+    const int tid = threadIdx.x;
+    load_wsplit(w, wref(a.wqkv, a.lo_qkv, (size_t)((tid >> 6) & 3) * 128 + (tid & 63) + (size_t)4 * 512));  // K weights fly during LayerNorm1
+    LnRows first;
+    ln_load(first, a.x + (size_t)blockIdx.x * HW * kDs, HW, tid);
+    ln_finish(first, A, a.eps1, tid);
+  }
+  int iter = 0;
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x, ++iter) {
+  // Everything below derives from a thread index the optimiser cannot see through: hoisting the sample-invariant
+  // bias loads and addresses out of the loop would cost more registers than the kernel has.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int cb = wave & 3, half = wave >> 2, tile0 = half * 4;
-  const int b = blockIdx.x;
-  const int HW = a.HW;
-  const float* xg = a.x + (size_t)b * HW * kDs;
   const size_t frag = (size_t)cb * 128 + lane;
   const int ch0 = cb * 32 + q4 * 8;
-
-  WSplit wa, wb;
-  load_wsplit(wa, a.wqkv, a.lo_qkv, frag + (size_t)4 * 512);  // K weights fly during staging and LayerNorm1
-  layernorm_to_planes<false>(xg, kDs, A, HW, a.eps1, tid);
-  __syncthreads();
+  const WRef wk = wref(a.wqkv, a.lo_qkv, frag + (size_t)4 * 512);
+  const float* xg = a.x + (size_t)b * HW * kDs;
+  const bool more = b + (int)gridDim.x < a.B;
+  LnRows rows;  // the next sample's input rows (this sample's again when there is none: loaded, never used)
+  ATRI_PHASE(0);
+  __syncthreads();  // LayerNorm1(x) planes complete
+  ATRI_PHASE(1);
 
   // ---- K (own 64 tokens of head cb) -> operand image in region B: [head][key tile][plane][lane]
   {
@@ -172,8 +307,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
       acc[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
       acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
     }
-    load_wsplit(wb, a.wqkv, a.lo_qkv, frag + (size_t)8 * 512);  // V weights fly during the K GEMM
-    gemm_split_k128<false>(acc, wa, A, tile0, l15, q4);
+    gemm_split_k128<false, true>(acc, w, A, tile0, l15, q4, wref(a.wqkv, a.lo_qkv, frag + (size_t)8 * 512));  // V weights refill the ring
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       short8 kh, kl;
@@ -183,24 +317,32 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
       img[64] = kl;
     }
   }
-  // ---- V with swapped operands: acc[t][n][j] = V[token (tile0 + t) * 16 + 4 q4 + j][dim perm(l15, n)]
-  short8 vth[4][2], vtl[4][2];  // after the exchange: V^T fragments of all 128 keys of head cb
+  ATRI_PHASE(2);
+  // ---- V^T of head cb for all 128 keys, swapped operands: acc[t][n][j] = V[token (4 r + t) * 16 + 4 q4 + j][dim perm(l15, n)]
+  short8 vth[4][2], vtl[4][2];
   {
     const int chp = (l15 >> 2) * 8 + (l15 & 3);
     const float bv0 = a.bqkv[2 * kDs + cb * 32 + chp], bv1 = a.bqkv[2 * kDs + cb * 32 + chp + 4];
-    float4v acc[4][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      acc[t][0] = (float4v){bv0, bv0, bv0, bv0};
-      acc[t][1] = (float4v){bv1, bv1, bv1, bv1};
+    for (int r = 0; r < 2; ++r) {
+      float4v acc[4][2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[t][0] = (float4v){bv0, bv0, bv0, bv0};
+        acc[t][1] = (float4v){bv1, bv1, bv1, bv1};
+      }
+      if (r == 0) {
+        gemm_split_k128<true, false>(acc, w, A, 0, l15, q4, none);
+      } else {
+        gemm_split_k128<true, true>(acc, w, A, 4, l15, q4, wref(a.wqkv, a.lo_qkv, frag));  // Q weights refill the ring
+      }
+#pragma unroll
+      for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) split8(acc[2 * kbl][n], acc[2 * kbl + 1][n], vth[2 * r + kbl][n], vtl[2 * r + kbl][n]);
     }
-    load_wsplit(wa, a.wqkv, a.lo_qkv, frag);  // Q weights fly during the V GEMM
-    gemm_split_k128<true>(acc, wb, A, tile0, l15, q4);
-#pragma unroll
-    for (int kbl = 0; kbl < 2; ++kbl)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) split8(acc[2 * kbl][n], acc[2 * kbl + 1][n], vth[kbl][n], vtl[kbl][n]);  // own key blocks, parked in slots 0..1
   }
+  ATRI_PHASE(3);
   // ---- Q: lane ends with dims 8 q4 .. 8 q4 + 7 of token (tile0 + t) * 16 + l15
   short8 qh[4], ql[4];
   {
@@ -213,91 +355,37 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
       acc[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
       acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
     }
-    gemm_split_k128<false>(acc, wa, A, tile0, l15, q4);
+    gemm_split_k128<false, false>(acc, w, A, tile0, l15, q4, none);
 #pragma unroll
     for (int t = 0; t < 4; ++t) split8(acc[t][0], acc[t][1], qh[t], ql[t]);
   }
-  __syncthreads();  // every wave is past its last read of LayerNorm1(x): region A becomes the V^T exchange image
-  {
-    // image: [head][key block 4][n 2][plane 2][lane]
-#pragma unroll
-    for (int kbl = 0; kbl < 2; ++kbl)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        short8* img = reinterpret_cast<short8*>(A) + ((size_t)((cb * 4 + half * 2 + kbl) * 2 + n) * 2) * 64 + lane;
-        img[0] = vth[kbl][n];
-        img[64] = vtl[kbl][n];
-      }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const short8* img = reinterpret_cast<const short8*>(A) + ((size_t)((cb * 4 + kb) * 2 + n) * 2) * 64 + lane;
-      vth[kb][n] = img[0];
-      vtl[kb][n] = img[64];
-    }
-  __syncthreads();  // region A is free again: the attention output goes there
+  // One dword of every 128-byte line of this sample's input rows: the output projection adds them as the residual, and
+  // by then they may have left L2 (the other workgroups of the XCD stream their own rows and outputs through it).
+  float touch = 0.f;
+  if (tid * 32 < HW * kDs) touch = xg[tid * 32];
+  ATRI_PHASE(4);
+  __syncthreads();  // K image complete; every wave is past its reads of LayerNorm1(x): region A takes the attention output
+  ATRI_PHASE(5);
 
   // ---- attention of head cb for this wave's four query tiles
   {
-    const int kt_full = HW >> 4;  // key tiles below this index hold no padding
     const short8* kimg = reinterpret_cast<const short8*>(Bq) + (size_t)(cb * 8) * 2 * 64 + lane;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      __builtin_amdgcn_sched_barrier(0);
-      float4v st[8];
-      float m = -1e30f;
-#pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
-        const short8 kh = kimg[(size_t)kt * 128], kl = kimg[(size_t)kt * 128 + 64];
-        st[kt] = mfma_split(kh, kl, qh[t], ql[t], (float4v){0.f, 0.f, 0.f, 0.f});
-        if (kt >= kt_full) {  // wave-uniform: only partly or wholly padded key tiles pay for masking
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (kt * 16 + q4 * 4 + j >= HW) st[kt][j] = -1e30f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
-      }
-      m = quad_row_max(m);
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          st[kt][j] = __builtin_amdgcn_exp2f(st[kt][j] - m);  // scores arrive in log2 units
-          sum += st[kt][j];
-        }
-      sum = quad_row_sum(sum);
-      float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        short8 ph, pl;
-        split8(st[2 * kb], st[2 * kb + 1], ph, pl);
-        o0 = mfma_split(vth[kb][0], vtl[kb][0], ph, pl, o0);
-        o1 = mfma_split(vth[kb][1], vtl[kb][1], ph, pl, o1);
-      }
-      const float inv = 1.0f / sum;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o0[j] *= inv;
-        o1[j] *= inv;
-      }
-      // lane holds channels cb*32 + q4*8 .. +7 of query (tile0 + t)*16 + l15
-      short8 oh, ol;
-      split8(o0, o1, oh, ol);
-      unsigned char* p = A + ((tile0 + t) * 16 + l15) * kStrideS + cb * 64 + q4 * 16;
-      *reinterpret_cast<short8*>(p) = oh;
-      *reinterpret_cast<short8*>(p + kPlane) = ol;
+    const WRef wo = wref(a.wo, a.lo_o, frag);
+    bool suspect;
+    if (HW > 112) {
+      suspect = attention_tiles<false, true>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
+    } else {
+      suspect = attention_tiles<false, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
     }
+    if (__builtin_amdgcn_ballot_w64(suspect) != 0) (void)attention_tiles<true, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
   }
-  load_wsplit(wb, a.wo, a.lo_o, frag);
+  ATRI_PHASE(6);
   __syncthreads();  // attention output complete; the K image in region B is dead
+  ATRI_PHASE(7);
 
   // ---- output projection + residual: y stays in fp32 registers until the end of the layer
   float4v y[4][2];
+  float2* stats = reinterpret_cast<float2*>(Bq);  // [token][channel block] (mean, M2) of 32 channels
   {
     float4 res[4][2];
 #pragma unroll
@@ -310,6 +398,9 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
         res[t][1] = p[1];
       }
     }
+    if (__float_as_uint(touch) == 0x7FC5A5A5u) __builtin_amdgcn_s_sleep(1);  // keeps the touch alive; never true for real data
+    if (a.phase_clock != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATRI_PHASE(17);
     float bias[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bias[i] = a.bo[ch0 + i];
@@ -318,20 +409,52 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
       y[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
       y[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
     }
-    gemm_split_k128<false>(y, wb, A, tile0, l15, q4);
-    load_wsplit(wa, a.w1, a.lo_1, frag);  // first W1 block flies during the y exchange and LayerNorm2
+    gemm_split_k128<false, true>(y, w, A, tile0, l15, q4, wref(a.w1, a.lo_1, frag));  // first W1 block refills the ring
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       y[t][0][0] += res[t][0].x; y[t][0][1] += res[t][0].y; y[t][0][2] += res[t][0].z; y[t][0][3] += res[t][0].w;
       y[t][1][0] += res[t][1].x; y[t][1][1] += res[t][1].y; y[t][1][2] += res[t][1].z; y[t][1][3] += res[t][1].w;
-      float* yp = reinterpret_cast<float*>(Bq) + (size_t)((tile0 + t) * 16 + l15) * kYPitch + ch0;
-      *reinterpret_cast<float4*>(yp) = make_float4(y[t][0][0], y[t][0][1], y[t][0][2], y[t][0][3]);
-      *reinterpret_cast<float4*>(yp + 4) = make_float4(y[t][1][0], y[t][1][1], y[t][1][2], y[t][1][3]);
+      // this wave's share of the row statistics: mean and centred sum of squares over its 32 channels
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += y[t][0][j] + y[t][1][j];
+      const float mean_w = quad_row_sum(s) * (1.0f / 32.0f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d0 = y[t][0][j] - mean_w, d1 = y[t][1][j] - mean_w;
+        m2 += d0 * d0 + d1 * d1;
+      }
+      m2 = quad_row_sum(m2);
+      if (q4 == 0) stats[((tile0 + t) * 16 + l15) * 4 + cb] = make_float2(mean_w, m2);
     }
   }
-  __syncthreads();  // y tile complete in region B; every wave is past its out-projection reads of region A
-  layernorm_to_planes<true>(reinterpret_cast<const float*>(Bq), kYPitch, A, HW, a.eps2, tid);
-  __syncthreads();  // LayerNorm2(y) planes complete; the fp32 y tile in region B is dead
+  ATRI_PHASE(8);
+  __syncthreads();  // statistics of all four channel blocks in place; every wave is past its out-projection reads of region A
+  ATRI_PHASE(9);
+  // ---- LayerNorm2(y) from registers into the planes of region A
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = (tile0 + t) * 16 + l15;
+    const float4 s01 = *reinterpret_cast<const float4*>(stats + r * 4), s23 = *reinterpret_cast<const float4*>(stats + r * 4 + 2);
+    const float mean = (s01.x + s01.z + s23.x + s23.z) * 0.25f;
+    const float e0 = s01.x - mean, e1 = s01.z - mean, e2 = s23.x - mean, e3 = s23.z - mean;
+    const float m2 = (s01.y + s01.w + s23.y + s23.w) + 32.0f * ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3));
+    const float rstd = r < HW ? rsqrtf(m2 * (1.0f / kDs) + a.eps2) : 0.f;  // rows beyond the sample become zero rows
+    float4v n0, n1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      n0[j] = (y[t][0][j] - mean) * rstd;
+      n1[j] = (y[t][1][j] - mean) * rstd;
+    }
+    short8 nh, nl;
+    split8(n0, n1, nh, nl);
+    unsigned char* p = A + r * kStrideS + cb * 64 + q4 * 16;
+    *reinterpret_cast<short8*>(p) = nh;
+    *reinterpret_cast<short8*>(p + kPlane) = nl;
+  }
+  __syncthreads();  // LayerNorm2(y) planes complete; the statistics in region B are dead
+  ATRI_PHASE(10);
 
   // ---- feed-forward: hidden layer in 128-wide halves through region B, second GEMM accumulates onto y (+ b2)
   {
@@ -358,9 +481,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
         acc[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
         acc[t][1] = (float4v){bias[4], bias[5], bias[6], bias[7]};
       }
-      load_wsplit(wb, a.w2, a.lo_2, frag + (size_t)h * 4 * 512);  // this half's W2 steps fly during the first GEMM
-      gemm_split_k128<false>(acc, wa, A, tile0, l15, q4);
-      if (h + 1 < HALVES) load_wsplit(wa, a.w1, a.lo_1, frag + (size_t)(h + 1) * 4 * 512);
+      gemm_split_k128<false, true>(acc, w, A, tile0, l15, q4, wref(a.w2, a.lo_2, frag + (size_t)h * 4 * 512));  // this half's W2 steps
       if (h > 0) __syncthreads();  // the previous half's second GEMM has finished reading the hidden tile
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -385,8 +506,15 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
         *reinterpret_cast<short8*>(p + kPlane) = hl;
       }
     }
-    __syncthreads();
-    gemm_split_k128<false>(y, wb, Bq, tile0, l15, q4);
+    ATRI_PHASE(11 + 2 * h);
+    __syncthreads();  // hidden tile complete; with the last half, every wave is also past its reads of region A
+    if (h + 1 < HALVES) {
+      gemm_split_k128<false, true>(y, w, Bq, tile0, l15, q4, wref(a.w1, a.lo_1, frag + (size_t)(h + 1) * 4 * 512));
+    } else {
+      ln_load(rows, more ? xg + (size_t)gridDim.x * HW * kDs : xg, HW, tid);  // next sample's rows fly during the last GEMM
+      gemm_split_k128<false, true>(y, w, Bq, tile0, l15, q4, wk);           // and the K weights refill the ring
+    }
+    ATRI_PHASE(12 + 2 * h);
   }
 
   float* og = a.out + (size_t)b * HW * kDs;
@@ -398,6 +526,10 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
     *reinterpret_cast<float4*>(op) = make_float4(y[t][0][0], y[t][0][1], y[t][0][2], y[t][0][3]);
     *reinterpret_cast<float4*>(op + 4) = make_float4(y[t][1][0], y[t][1][1], y[t][1][2], y[t][1][3]);
   }
+  ATRI_PHASE(18);
+  if (more) ln_finish(rows, A, a.eps1, tid);  // region A is free since the barrier before the last GEMM
+  ATRI_PHASE(19);
+  }
 }
 
 namespace {
@@ -408,12 +540,32 @@ int launch_enc(const SplitEncArgs& a, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)encoder_layer_split_kernel<HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kRegion);
     attr = true;
   }
-  hipLaunchKernelGGL((encoder_layer_split_kernel<HALVES>), dim3(a.B), dim3(512), 2 * kRegion, stream, a);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -20;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  hipLaunchKernelGGL((encoder_layer_split_kernel<HALVES>), dim3(a.B < cus ? a.B : cus), dim3(512), 2 * kRegion, stream, a);
   return hip_err(hipGetLastError());
 }
 }  // namespace
 
+namespace {
+long long* g_phase_clock = nullptr;
+int g_phase_block = 0;
+}  // namespace
+
 extern "C" {
+
+// Diagnostics: workgroup `block` of every following atri_split_encoder_layer launch stores the shader clock at its
+// phase boundaries into clock[0..19] (device memory); nullptr switches it off.
+int atri_split_encoder_phase_clock(long long* clock, int block) {
+  g_phase_clock = clock;
+  g_phase_block = block;
+  return 0;
+}
 
 // One encoder layer, fp32-grade: x [B, HW, 128] f32 -> out [B, HW, 128] f32 (out != x).  LayerNorm affine parts are
 // folded into (wqkv, bqkv) and (w1, b1) by the host; Q weights are pre-scaled by log2(e) / sqrt(32).
@@ -434,6 +586,7 @@ int atri_split_encoder_layer(const float* x, float* out, const void* wqkv, long 
   a.w2 = (const unsigned short*)w2; a.lo_2 = lo_2; a.b2 = b2;
   a.B = B; a.HW = HW; a.F = F; a.act = act;
   a.eps1 = eps1; a.eps2 = eps2;
+  a.phase_clock = g_phase_clock; a.phase_block = g_phase_block;
   switch (F / 128) {
     case 1: return launch_enc<1>(a, stream);
     case 2: return launch_enc<2>(a, stream);

@@ -130,7 +130,7 @@ def test_tree_search_equals_host_search(leaves, large):
         assert hv.sum() > 0
 
 
-def _actor(games=48, sims=12, graphs=True, leaves=1, seed=7, dtype="bf16", model=None):
+def _actor(games=48, sims=12, graphs=True, leaves=1, seed=7, dtype="bf16", model=None, hip_engine=None):
     from alphatriangle_amd.models.network import NeuralNetwork
     from alphatriangle_amd.rl.core.device_buffer import DeviceReplayBuffer
     from alphatriangle_amd.rl.self_play.gpu_actor import GpuSelfPlayActor
@@ -141,7 +141,7 @@ def _actor(games=48, sims=12, graphs=True, leaves=1, seed=7, dtype="bf16", model
     tc = TrainConfig(DEVICE="cuda", BUFFER_CAPACITY=20000, MIN_BUFFER_SIZE_TO_TRAIN=64, BATCH_SIZE=32, N_STEP_RETURNS=3, MAX_TRAINING_STEPS=1000)
     sc = SystemConfig(GAMES_PER_GPU=games, LEAVES_PER_TREE=leaves, USE_HIP_GRAPHS=graphs, INFERENCE_DTYPE=dtype)
     mcts = AlphaTriangleMCTSConfig(max_simulations=sims, max_depth=5)
-    net = NeuralNetwork(mc, env, tc, dev, inference_dtype=dtype)
+    net = NeuralNetwork(mc, env, tc, dev, use_hip_engine=hip_engine, inference_dtype=dtype)
     replay = DeviceReplayBuffer(tc, env, mc, dev, sc)
     actor = GpuSelfPlayActor(env, mc, mcts, tc, sc, net, replay, dev, seed=seed)
     return actor, replay, tc
@@ -184,13 +184,15 @@ def test_per_game_step_metrics_and_slot_census():
     assert sum(c.values()) == actor.G * actor.waves_per_move and c["expand"] > 0
 
 
-@pytest.mark.parametrize("evaluator", ["engine", "module"])
+@pytest.mark.parametrize("evaluator", ["engine-bf16", "engine-fp32", "module"])
 def test_non_finite_network_output_raises_and_every_kernel_finishes(evaluator):
     """A diverged learner must not poison the replay silently (alphatriangle/nn/network.py:177-191,260-274)."""
     from alphatriangle_amd.models.network import NetworkEvaluationError
 
-    actor, replay, _ = _actor(games=16, sims=6, dtype="bf16" if evaluator == "engine" else "fp32")
-    assert type(actor.evaluator).__name__ == ("EngineEvaluator" if evaluator == "engine" else "ModuleEvaluator")
+    actor, replay, _ = _actor(games=16, sims=6, dtype="bf16" if evaluator == "engine-bf16" else "fp32",
+                              hip_engine=False if evaluator == "module" else None)
+    assert type(actor.evaluator).__name__ == ("ModuleEvaluator" if evaluator == "module" else "EngineEvaluator")
+    assert actor.dtype == ("bf16" if evaluator == "engine-bf16" else "fp32")
     actor.play_move()  # healthy move first
     with torch.no_grad():
         actor.nn._orig_model.policy_head[-1].bias[3] = float("nan")  # poisoned from the host
