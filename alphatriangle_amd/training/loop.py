@@ -388,6 +388,29 @@ class TrainingLoop:
         if self.trieye_actor:
             self.trieye_actor.process_and_log(self.global_step)
 
+    def _sigint_requests_stop(self):  # noqa: ANN202
+        """While the loop runs, the first Ctrl-C is a stop request instead of an exception.
+
+        The round in progress finishes and the stop travels through the next negotiation, so the ranks of a multi-GPU
+        job leave together (an exception would take this rank out between two collectives and leave the others waiting
+        for it until their time-out).  A second Ctrl-C raises KeyboardInterrupt as usual.  Returns the undo function;
+        outside the main thread (tests, embedded use) nothing is installed.
+        """
+        import signal
+
+        if threading.current_thread() is not threading.main_thread():
+            return lambda: None
+        previous = signal.getsignal(signal.SIGINT)
+
+        def on_sigint(signum, frame):  # noqa: ANN001, ARG001
+            if self.stop_requested.is_set():
+                raise KeyboardInterrupt
+            logger.warning("Interrupt received: stopping after this round (interrupt again to abort).")
+            self.request_stop()
+
+        signal.signal(signal.SIGINT, on_sigint)
+        return lambda: signal.signal(signal.SIGINT, previous)
+
     # ------------------------------------------------------------------ main loop
     def run(self) -> None:
         from ..parallel.dist import PeerLostError
@@ -395,6 +418,7 @@ class TrainingLoop:
         target = self.train_config.MAX_TRAINING_STEPS
         logger.info("Training starts: %s.", f"{target} learner steps" if target else "no step limit")
         self.start_time = time.time()
+        restore_sigint = self._sigint_requests_stop()
         try:
             self.source.open()
             while True:
@@ -423,6 +447,7 @@ class TrainingLoop:
             self.training_exception = exc
             self.request_stop()
         finally:
+            restore_sigint()
             if self.training_exception is not None or not (target is not None and self.global_step >= target):
                 self.training_complete = False
             logger.info("Training loop ended after %d rounds (complete: %s, failed: %s).", self.rounds, self.training_complete,

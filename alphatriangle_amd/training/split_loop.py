@@ -383,6 +383,7 @@ class SplitRoleLoop(TrainingLoop):
         logger.info("Split layout: rank %d is %s; %d learner(s), %d actor(s).", ctx.rank, "learner" if ctx.is_learner else "actor",
                     len(ctx.layout.learner_ranks), len(ctx.layout.actor_ranks))
         self.start_time = time.time()
+        restore_sigint = self._sigint_requests_stop()  # first Ctrl-C: the role loops see stop_requested and leave in order
         try:
             if ctx.is_learner:
                 self._run_learner()
@@ -407,6 +408,7 @@ class SplitRoleLoop(TrainingLoop):
             except Exception:  # pragma: no cover
                 pass
         finally:
+            restore_sigint()
             if self.training_exception is not None:
                 self.training_complete = False
             wall = max(time.time() - self.start_time, 1e-9)

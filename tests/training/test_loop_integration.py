@@ -116,6 +116,31 @@ def test_loop_resume_counters_and_stop(components, monkeypatch):
     assert not loop.training_complete and loop.global_step == 12
 
 
+def test_first_interrupt_is_a_stop_request_and_the_round_finishes(components, monkeypatch):
+    """SIGINT while the loop runs: no exception, the current round completes, the loop ends through its normal exit."""
+    import os
+    import signal
+
+    monkeypatch.setattr("alphatriangle_amd.training.loop.WorkerManager", FakeManager)
+    components.train_config.MAX_TRAINING_STEPS = 10_000
+    loop = TrainingLoop(components)
+    calls = {"n": 0}
+    real = components.trainer.train_step.return_value
+
+    def step(*_a, **_k):
+        calls["n"] += 1
+        if calls["n"] == 7:
+            os.kill(os.getpid(), signal.SIGINT)  # delivered to the main thread, i.e. inside this round
+        return real
+
+    components.trainer.train_step.side_effect = step
+    before = signal.getsignal(signal.SIGINT)
+    loop.run()
+    assert signal.getsignal(signal.SIGINT) is before, "the loop must restore the previous handler"
+    assert loop.training_exception is None and not loop.training_complete
+    assert loop.global_step == 7 and components.buffer.update_priorities.call_count == 7  # the interrupted round was completed
+
+
 def test_loop_survives_training_exception(components, monkeypatch):
     monkeypatch.setattr("alphatriangle_amd.training.loop.WorkerManager", FakeManager)
     components.trainer.train_step.side_effect = RuntimeError("boom")
