@@ -103,4 +103,15 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 
 inline int hip_err(hipError_t e) { return (int)e; }
 
+// Live row count for the inference engines' batch kernels.  A search wave writes only the leaves that need an evaluation
+// (densely, rows 0 .. n-1) and leaves n in device memory; the engine kernels are launched for the full batch capacity
+// and every workgroup beyond row n ends at once.  The pointer is host state of the library: atri_set_live_count()
+// sets it, every engine launch made while it is set carries it (also into a captured graph), nullptr = all rows.
+const int* live_count_ptr();
+__device__ __forceinline__ int live_rows(const int* live, int capacity) {
+  if (live == nullptr) return capacity;
+  const int n = *live;
+  return n < capacity ? n : capacity;
+}
+
 }  // namespace atrihip

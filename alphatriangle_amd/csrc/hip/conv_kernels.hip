@@ -28,6 +28,7 @@ struct RowConvArgs {
   const float* post_add;           // [HW, Cout] f32 or nullptr (added after the activation)
   unsigned short* out;             // [B, HW, Cout] bf16
   int B, H, W, HW, Cin, Cout, act, n_blocks, log2_cpr, out_off, ymagic;
+  const int* live;                 // device row count (nullptr: B rows), see common.hpp
   // FIRST instantiation only: the network's first layer (1 input channel, 3x3) is evaluated while staging
   const float* grid;     // [B, HW] f32 board planes
   const float* w_first;  // [9][Cin] f32 (BatchNorm folded)
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x;
+  if (b >= live_rows(a.live, a.B)) return;  // whole workgroup, before any barrier
   // row pitch = Cin*2 + 32 bytes = an even, non-multiple-of-4 count of 16-byte slots: the 16 lanes that one
   // ds_read_b128 cycle serves (8 rows at slot q, 8 rows at slot q+1) then hit 16 different bank quads for every tap
   constexpr int stride = CIN * 2 + 32;
@@ -386,6 +388,7 @@ static int rowconv_impl(const void* in, const void* w, const float* bias, const 
   a.post_add = post_add;
   a.out = (unsigned short*)out;
   a.B = B;
+  a.live = live_count_ptr();
   a.H = H;
   a.W = W;
   a.HW = H * W;
@@ -438,6 +441,7 @@ int atri_rowconv_first(const float* grid, const float* w_first, const float* b_f
   a.bias = bias;
   a.out = (unsigned short*)out;
   a.B = B;
+  a.live = live_count_ptr();
   a.H = H;
   a.W = W;
   a.HW = H * W;
@@ -481,6 +485,7 @@ int atri_rowconv_pair(const void* in, const void* w1, const float* b1, const voi
   a.post_add = post_add;
   a.out = (unsigned short*)out;
   a.B = B;
+  a.live = live_count_ptr();
   a.H = H;
   a.W = W;
   a.HW = H * W;
@@ -515,6 +520,7 @@ static int rowconv_stem_impl(const float* grid, const float* w_first, const floa
   a.post_add = post_add;
   a.out = (unsigned short*)out;
   a.B = B;
+  a.live = live_count_ptr();
   a.H = H;
   a.W = W;
   a.HW = H * W;

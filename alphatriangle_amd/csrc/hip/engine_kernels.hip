@@ -46,6 +46,11 @@ struct TreeBufs {
   // per-tree counters, private to the tree's wave (plain read-modify-write, summed on the host once per move):
   // [0..3] leaf slots by kind (none / expand / terminal / depth cap), [4] network evaluations that were not finite
   int32_t* census;     // [G][kCensus]
+  // Batch compaction: with a row counter, a simulation wave writes the feature rows of the leaves that need an
+  // evaluation densely (row = counter++, one atomic per leaf) and remembers the row per slot; the counter's final value
+  // is the live row count of the network kernels that follow.  Without one (nullptr) a slot's row is the slot itself.
+  int32_t* slot_row;     // [G*L]
+  int32_t* live_cursor;  // [1], zeroed by the caller before every selecting wave
   int32_t G, C, A, L, P, other_dim, logit_stride, pad;
 };
 constexpr int kCensus = 8;
@@ -439,8 +444,9 @@ __global__ void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int d
       float value = 0.0f;
       if (kind == kSlotExpand) {
         const State st = states[leaf];
-        bool bad = wave_init_edges(g, st, edges + (size_t)leaf * A, tb.nn_logits + (size_t)slot * tb.logit_stride, lane);
-        value = tb.nn_value[slot];
+        const int row = tb.live_cursor != nullptr ? tb.slot_row[slot] : slot;
+        bool bad = wave_init_edges(g, st, edges + (size_t)leaf * A, tb.nn_logits + (size_t)row * tb.logit_stride, lane);
+        value = tb.nn_value[row];
         if (!(fabsf(value) < INFINITY)) {
           bad = true;
           value = 0.0f;
@@ -582,8 +588,17 @@ __global__ void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int d
         }
         leaf = nn;
         kind = st.over ? kSlotTerminal : kSlotExpand;
-        if (kind == kSlotExpand)
-          wave_features(g, st, tb.nn_grid + (size_t)slot * g.cells, tb.nn_other + (size_t)slot * tb.other_dim, tb.other_dim, lane);
+        if (kind == kSlotExpand) {
+          int row = slot;
+          if (tb.live_cursor != nullptr) {
+            if (lane == 0) {
+              row = atomicAdd(tb.live_cursor, 1);
+              tb.slot_row[slot] = row;
+            }
+            row = __shfl(row, 0, 64);
+          }
+          wave_features(g, st, tb.nn_grid + (size_t)row * g.cells, tb.nn_other + (size_t)row * tb.other_dim, tb.other_dim, lane);
+        }
         __syncthreads();
         break;
       }

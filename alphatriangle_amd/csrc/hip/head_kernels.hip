@@ -27,6 +27,7 @@ struct HeadsArgs {
   float* values;               // [B]
   int B, SK, act, nbp, a_store, logit_stride, atoms, atoms_store, value_stride;
   float vmin, dz;
+  const int* live;             // device row count (nullptr: B rows), see common.hpp; B stays the slab pitch
 };
 
 namespace {
@@ -70,6 +71,8 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadsArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b0 = blockIdx.x * kHeadRows;
+  const int nB = live_rows(a.live, a.B);
+  if (b0 >= nB) return;  // whole workgroup, before any barrier
 
   // first-layer weight fragments of both heads: requested now, consumed after the slab reduction
   const short8* wp1 = reinterpret_cast<const short8*>(a.wp1) + wave * 128 + lane;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadsArgs a) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    if (b < a.B) {
+    if (b < nB) {
       const float4* bp = reinterpret_cast<const float4*>(a.fc_bias + n0);
       const float4 c0 = bp[0], c1 = bp[1];
       v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadsArgs a) {
         const int c = ch + n * 4 + j;
         const float v = acc[n][j] + a.bv2[c];
         vl[l15][c] = v;
-        if (b < a.B && c < a.atoms_store) a.vlogits[(size_t)b * a.value_stride + c] = v;
+        if (b < nB && c < a.atoms_store) a.vlogits[(size_t)b * a.value_stride + c] = v;
       }
     }
   }
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadsArgs a) {
     float4v acc[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
     gemm128(reinterpret_cast<const short8*>(a.wp2) + ((size_t)nb * 16 + wave) * 128 + lane, p_tile + lane_off, acc);
     const int c0 = nb * 128 + ch;
-    if (b < a.B && c0 < a.a_store) {  // a_store is a multiple of 8: a lane's 8 channels are all inside or all outside
+    if (b < nB && c0 < a.a_store) {  // a_store is a multiple of 8: a lane's 8 channels are all inside or all outside
       const float4* bp = reinterpret_cast<const float4*>(a.bp2 + c0);
       const float4 bl = bp[0], bh = bp[1];
       float4* out = reinterpret_cast<float4*>(a.logits + (size_t)b * a.logit_stride + c0);
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadsArgs a) {
       s += __shfl_xor(s, off, 64);
       e += __shfl_xor(e, off, 64);
     }
-    if (l == 0 && b0 + r < a.B) a.values[b0 + r] = e / s;
+    if (l == 0 && b0 + r < nB) a.values[b0 + r] = e / s;
   }
 }
 
@@ -220,6 +223,7 @@ int atri_heads(const float* slabs, int SK, const float* fc_bias, const void* wp1
   a.vlogits = vlogits;
   a.values = values;
   a.B = B;
+  a.live = live_count_ptr();
   a.SK = SK;
   a.act = act;
   a.nbp = nbp;

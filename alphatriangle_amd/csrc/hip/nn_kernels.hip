@@ -508,11 +508,13 @@ __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned s
                                                                 const float* __restrict__ g, const float* __restrict__ bt,
                                                                 float eps, const unsigned short* __restrict__ Wp,
                                                                 float* __restrict__ slabs, int B, int HW, int other_pad,
-                                                                int N, int steps_per_split) {
+                                                                int N, int steps_per_split, const int* __restrict__ live) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[MT * 16 * 272];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b0 = blockIdx.x * (MT * 16);
+  const int nB = live_rows(live, B);  // rows that hold leaves; B stays the slab pitch
+  if (b0 >= nB) return;               // whole workgroup, before any barrier
   const int feat_steps = HW * 4;
   const int total_steps = feat_steps + (other_pad >> 5);
   const int s_begin = blockIdx.y * steps_per_split;
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned s
     for (int i = 0; i < MT; ++i) {
       const int c = tid + i * 256, r = c >> 4, cc = c & 15;
       v[i] = make_uint4(0, 0, 0, 0);
-      if (s0 < s_end && b0 + r < B) {
+      if (s0 < s_end && b0 + r < nB) {
         if (s0 < feat_steps) {
           v[i] = *reinterpret_cast<const uint4*>(rows + ((size_t)(b0 + r) * HW + (s0 >> 2)) * 128 + cc * 8);
         } else {  // the "other" features: converted from the caller's f32 rows on the fly (zero padded to other_pad)
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned s
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int bi = b0 + t * 16 + l15;
-    if (bi >= B) continue;
+    if (bi >= nB) continue;
     float* op = slab + (size_t)bi * 128 + ch0;
     *reinterpret_cast<float4*>(op) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
     *reinterpret_cast<float4*>(op + 4) = make_float4(acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]);
@@ -690,7 +692,22 @@ int launch_tile_gemm(const TileGemmArgs& a, hipStream_t stream, int dbg) {
 }
 }  // namespace
 
+namespace {
+const int* g_live_count = nullptr;
+}  // namespace
+namespace atrihip {
+const int* live_count_ptr() { return g_live_count; }
+}  // namespace atrihip
+
 extern "C" {
+
+// Device row count consulted by the engines' batch kernels launched from now on (nullptr: every launch covers its
+// whole batch).  See common.hpp: live_rows.
+int atri_set_live_count(const int* count) {
+  g_live_count = count;
+  return 0;
+}
+
 
 
 int atri_tile_gemm(const void* in, const void* w, const float* bias, const void* residual, const float* post_add,
@@ -835,11 +852,11 @@ int atri_fc_rows_splitk(const void* rows, const float* other, int other_dim, con
   if (B >= 2048)  // enough samples to fill the chip with 128-sample workgroups
     hipLaunchKernelGGL(fc_rows_splitk_kernel<8>, dim3((B + 127) / 128, SK), dim3(256), 0, stream, (const unsigned short*)rows,
                        other, other_dim, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
-                       steps_per_split);
+                       steps_per_split, live_count_ptr());
   else
     hipLaunchKernelGGL(fc_rows_splitk_kernel<4>, dim3((B + 63) / 64, SK), dim3(256), 0, stream, (const unsigned short*)rows,
                        other, other_dim, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
-                       steps_per_split);
+                       steps_per_split, live_count_ptr());
   return hip_err(hipGetLastError());
 }
 

@@ -6,7 +6,8 @@
 // fp32 operand as x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits) and computes
 //     W x  ~=  W_hi x_hi + W_lo x_hi + W_hi x_lo          (the dropped W_lo x_lo term is 2^-16 relative)
 // on the bf16 matrix cores: 3 MFMAs per product instead of 1, accumulators and everything element-wise in fp32.
-// Measured against an fp64 evaluation the result is as close as PyTorch's fp32 path (tests/test_gpu_nn_fp32.py).
+// Measured against an fp64 evaluation of the default network the logits are within 4 - 6e-6 (PyTorch's fp32 path:
+// 3 - 6e-7; a plain bf16 evaluation: ~1e-2) - see tests/test_gpu_nn_fp32.py.
 //
 // Layers served: the conv stem and both convolutions of every residual block
 // (alphatriangle/nn/model.py:20-37 conv_block, :40-59 ResidualBlock), BatchNorm folded.
@@ -33,6 +34,7 @@ struct SplitConvArgs {
   float* out;              // [B, HW, Cout] f32
   long long lo_off, lo_off2;
   int B, H, W, HW, Cin, Cout, act, ymagic;
+  const int* live;       // device row count (nullptr: B rows), see common.hpp
   // FIRST: the network's first layer (1 input channel, 3x3) is evaluated while staging
   const float* grid;     // [B, HW] f32 board planes
   const float* w_first;  // [9][Cin] f32 (BatchNorm folded)
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x;
+  if (b >= live_rows(a.live, a.B)) return;  // whole workgroup, before any barrier
   constexpr int stride = CIN * 2 + 32;
   constexpr int stride2 = CIN2 * 2 + 32;
   constexpr int plane = kTileRows * stride, plane2 = kTileRows * stride2;
@@ -333,7 +336,7 @@ int launch_split(const SplitConvArgs& a, int lds, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)rowconv_split_kernel<CIN, FIRST, PAIR, CIN2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((rowconv_split_kernel<CIN, FIRST, PAIR, CIN2>), dim3(a.B), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((rowconv_split_kernel<CIN, FIRST, PAIR, CIN2>), dim3(a.B), dim3(256), lds, stream, a);  // a.live set by the callers
   return hip_err(hipGetLastError());
 }
 
@@ -370,6 +373,7 @@ int atri_split_conv_pair(const float* in, const void* w1, long long lo1, const f
   a.post_add = post_add;
   a.out = out;
   a.B = B; a.H = H; a.W = W; a.HW = H * W; a.Cin = C; a.Cout = C; a.act = act;
+  a.live = live_count_ptr();
   a.ymagic = 65536 / W + 1;
   const int tiles = 2 * kTileRows * (C * 2 + 32);
   const int lds = tiles > kOutBytes ? tiles : kOutBytes;
@@ -394,6 +398,7 @@ int atri_split_conv_stem(const float* grid, const float* w_first, const float* b
   a.post_add = post_add;
   a.out = out;
   a.B = B; a.H = H; a.W = W; a.HW = H * W; a.Cin = C0; a.Cout = C2; a.act = act;
+  a.live = live_count_ptr();
   a.grid = grid;
   a.w_first = w_first;
   a.b_first = b_first;
@@ -422,6 +427,7 @@ int atri_split_conv(const float* in, const void* w, long long lo, const float* b
   a.post_add = post_add;
   a.out = out;
   a.B = B; a.H = H; a.W = W; a.HW = H * W; a.Cin = Cin; a.Cout = Cout; a.act = act;
+  a.live = live_count_ptr();
   a.ymagic = 65536 / W + 1;
   const int tiles = 2 * kTileRows * (Cin * 2 + 32);
   const int lds = tiles > kOutBytes ? tiles : kOutBytes;

@@ -20,11 +20,13 @@ __global__ __launch_bounds__(256, 2) void fc_rows_split_kernel(const float* __re
                                                               const float* __restrict__ bt, float eps,
                                                               const unsigned short* __restrict__ Wp, long long lo_off,
                                                               float* __restrict__ slabs, int B, int HW, int other_pad, int N,
-                                                              int steps_per_split) {
+                                                              int steps_per_split, const int* __restrict__ live) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[2][MT * 16 * kPitch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b0 = blockIdx.x * (MT * 16);
+  const int nB = live_rows(live, B);  // rows that hold leaves; B stays the slab pitch
+  if (b0 >= nB) return;               // whole workgroup, before any barrier
   const int feat_steps = HW * 4;
   const int total_steps = feat_steps + (other_pad >> 5);
   const int s_begin = blockIdx.y * steps_per_split;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void fc_rows_split_kernel(const float* __re
     for (int i = 0; i < MT; ++i) {
       const int c = tid + i * 256, r = c >> 4, cc = c & 15;
       v[i][0] = v[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (s0 < s_end && b0 + r < B) {
+      if (s0 < s_end && b0 + r < nB) {
         if (s0 < feat_steps) {
           const float4* p = reinterpret_cast<const float4*>(rows + ((size_t)(b0 + r) * HW + (s0 >> 2)) * 128 + cc * 8);
           v[i][0] = p[0];
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void fc_rows_split_kernel(const float* __re
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int bi = b0 + t * 16 + l15;
-    if (bi >= B) continue;
+    if (bi >= nB) continue;
     float* op = slab + (size_t)bi * 128 + ch0;
     *reinterpret_cast<float4*>(op) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
     *reinterpret_cast<float4*>(op + 4) = make_float4(acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]);
@@ -153,6 +155,7 @@ struct SplitHeadsArgs {
   float* values;               // [B]
   int B, SK, act, nbp, a_store, logit_stride, atoms, atoms_store, value_stride;
   float vmin, dz;
+  const int* live;             // device row count (nullptr: B rows), see common.hpp; B stays the slab pitch
 };
 
 namespace {
@@ -202,6 +205,8 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b0 = blockIdx.x * kHeadRowsS;
+  const int nB = live_rows(a.live, a.B);
+  if (b0 >= nB) return;  // whole workgroup, before any barrier
 
   // ---- shared FC: sum the split-K slabs, bias, activation (fp32) -> s_tile planes (thread = sample, 8 channels) ----
   {
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    if (b < a.B) {
+    if (b < nB) {
       const float4* bp = reinterpret_cast<const float4*>(a.fc_bias + n0);
       const float4 c0 = bp[0], c1 = bp[1];
       v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
         const int c = ch + n * 4 + j;
         const float v = acc[n][j] + a.bv2[c];
         vl[l15][c] = v;
-        if (b < a.B && c < a.atoms_store) a.vlogits[(size_t)b * a.value_stride + c] = v;
+        if (b < nB && c < a.atoms_store) a.vlogits[(size_t)b * a.value_stride + c] = v;
       }
     }
   }
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
     float4v acc[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
     gemm128_split(a.wp2, a.lo_p2, ((size_t)nb * 16 + wave) * 128 + lane, p_tile[0] + lane_off, p_tile[1] + lane_off, acc);
     const int c0 = nb * 128 + ch;
-    if (b < a.B && c0 < a.a_store) {
+    if (b < nB && c0 < a.a_store) {
       const float4* bp = reinterpret_cast<const float4*>(a.bp2 + c0);
       const float4 bl = bp[0], bh = bp[1];
       float4* out = reinterpret_cast<float4*>(a.logits + (size_t)b * a.logit_stride + c0);
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
       s += __shfl_xor(s, off, 64);
       e += __shfl_xor(e, off, 64);
     }
-    if (l == 0 && b0 + r < a.B) a.values[b0 + r] = e / s;
+    if (l == 0 && b0 + r < nB) a.values[b0 + r] = e / s;
   }
 }
 
@@ -329,7 +334,7 @@ int atri_split_fc_rows(const float* rows, const float* other, int other_dim, con
   // 64 samples per workgroup: with three MFMA passes per product the loop is matrix-core bound, and the 128-sample
   // variant of the bf16 kernel (half the weight reads from L2) does not fit the register file next to the lo fragments
   hipLaunchKernelGGL(fc_rows_split_kernel<4>, dim3((B + 63) / 64, SK), dim3(256), 0, stream, rows, other, other_dim, g, bt, eps,
-                       (const unsigned short*)Wp, lo_off, slabs, B, HW, other_pad, N, steps_per_split);
+                       (const unsigned short*)Wp, lo_off, slabs, B, HW, other_pad, N, steps_per_split, live_count_ptr());
   return hip_err(hipGetLastError());
 }
 
@@ -355,6 +360,7 @@ int atri_split_heads(const float* slabs, int SK, const float* fc_bias, const voi
   a.B = B; a.SK = SK; a.act = act; a.nbp = nbp; a.a_store = a_store; a.logit_stride = logit_stride;
   a.atoms = atoms; a.atoms_store = atoms_store; a.value_stride = value_stride;
   a.vmin = vmin; a.dz = dz;
+  a.live = live_count_ptr();
   hipLaunchKernelGGL(heads_split_kernel, dim3((B + kHeadRowsS - 1) / kHeadRowsS), dim3(256), 0, stream, a);
   return hip_err(hipGetLastError());
 }

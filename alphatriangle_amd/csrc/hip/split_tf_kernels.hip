@@ -40,6 +40,7 @@ struct SplitEncArgs {
   long long lo_qkv, lo_o, lo_1, lo_2;
   int B, HW, F, act;
   float eps1, eps2;
+  const int* live;            // device row count (nullptr: B rows), see common.hpp
   long long* phase_clock;     // diagnostics: workgroup `phase_block` stores the shader clock at its phase boundaries
   int phase_block;
 };
@@ -264,6 +265,8 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   unsigned char* A = smem;
   unsigned char* Bq = smem + kRegion;
   const int HW = a.HW;
+  const int nB = live_rows(a.live, a.B);
+  if ((int)blockIdx.x >= nB) return;  // whole workgroup, before any barrier
   const WRef none{nullptr, nullptr};
 
   // The workgroup is persistent: it walks samples blockIdx.x, blockIdx.x + gridDim.x, ...  The input rows of the next
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
     ln_finish(first, A, a.eps1, tid);
   }
   int iter = 0;
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x, ++iter) {
+  for (int b = blockIdx.x; b < nB; b += gridDim.x, ++iter) {
   // Everything below derives from a thread index the optimiser cannot see through: hoisting the sample-invariant
   // bias loads and addresses out of the loop would cost more registers than the kernel has.
   int tid = threadIdx.x;
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   const int ch0 = cb * 32 + q4 * 8;
   const WRef wk = wref(a.wqkv, a.lo_qkv, frag + (size_t)4 * 512);
   const float* xg = a.x + (size_t)b * HW * kDs;
-  const bool more = b + (int)gridDim.x < a.B;
+  const bool more = b + (int)gridDim.x < nB;
   LnRows rows;  // the next sample's input rows (this sample's again when there is none: loaded, never used)
   ATRI_PHASE(0);
   __syncthreads();  // LayerNorm1(x) planes complete
@@ -587,6 +590,7 @@ int atri_split_encoder_layer(const float* x, float* out, const void* wqkv, long 
   a.B = B; a.HW = HW; a.F = F; a.act = act;
   a.eps1 = eps1; a.eps2 = eps2;
   a.phase_clock = g_phase_clock; a.phase_block = g_phase_block;
+  a.live = live_count_ptr();
   switch (F / 128) {
     case 1: return launch_enc<1>(a, stream);
     case 2: return launch_enc<2>(a, stream);

@@ -187,6 +187,7 @@ struct AttnBlockArgs {
   const float* ln_b;
   int B, HW;
   float ln_eps;
+  const int* live;             // device row count (nullptr: B rows), see common.hpp; honoured by encoder_layer_kernel
 };
 
 // The query tiles of one head (wave) of attn_body: scores key-major from register fragments, softmax, P.V, result rows
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(256, 2) void encoder_layer_kernel(EncoderLayerArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x;
+  if (b >= live_rows(e.attn.live, e.attn.B)) return;  // whole workgroup, before any barrier
   const int HW = e.attn.HW;
   const int ch0 = wave * 32 + q4 * 8;
   float4v acc_o[8][2];
@@ -1289,7 +1291,7 @@ int atri_encoder_layer(const void* x, void* out, const void* wqkv, const float* 
   if (x == out) return -13;  // the residual is read after other rows of the sample's output could have been written
   EncoderLayerArgs e{};
   e.attn = AttnBlockArgs{(const unsigned short*)x, (unsigned short*)out, (const unsigned short*)wqkv, bqkv,
-                         (const unsigned short*)wo, bo, ln1_g, ln1_b, B, HW, ln1_eps};
+                         (const unsigned short*)wo, bo, ln1_g, ln1_b, B, HW, ln1_eps, live_count_ptr()};
   e.w1 = (const unsigned short*)w1;
   e.b1 = b1;
   e.w2 = (const unsigned short*)w2;

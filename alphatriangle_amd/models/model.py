@@ -26,6 +26,24 @@ def _grad_dtype(partial: torch.Tensor) -> torch.dtype:
     return torch.float32 if partial.dtype in (torch.bfloat16, torch.float16) else partial.dtype
 
 
+def _autocast_dtype(t: torch.Tensor) -> torch.dtype | None:
+    """The dtype autocast would run a GEMM on ``t``'s device in, or ``None`` outside autocast."""
+    if t.is_cuda and torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
+    return None
+
+
+def _as_dtype(weight: torch.Tensor, dtype: torch.dtype | None) -> torch.Tensor:
+    """``weight`` in ``dtype``: the optimizer-side low-precision view when one is attached
+    (``ops.optim.FlatParameterSpace.refresh_shadow``), else a cast."""
+    if dtype is None or weight.dtype == dtype:
+        return weight
+    shadow = getattr(weight, "_atri_shadow", None)
+    if shadow is not None and shadow.dtype == dtype and shadow.shape == weight.shape:
+        return shadow
+    return weight.to(dtype)
+
+
 def _split_count(n: int, limit: int = 32, min_chunk: int = 512) -> int:
     """Largest divisor of ``n`` that is at most ``limit`` and leaves chunks of at least ``min_chunk``."""
     for s in range(min(limit, max(1, n // min_chunk)), 1, -1):
@@ -64,16 +82,19 @@ class _ConvGemm(torch.autograd.Function):
     """
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x: torch.Tensor, weight: torch.Tensor, ph: int, pw: int) -> torch.Tensor:  # noqa: ANN001
-        b, _, h, w = x.shape
-        cout, _, kh, kw = weight.shape
-        cols = _patch_matrix(x, kh, kw, ph, pw)
-        ctx.save_for_backward(cols, weight)
-        ctx.geom = (b, h, w, ph, pw)
-        oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-        out = weight.reshape(cout, -1) @ cols  # [Cout, B*oh*ow]
-        return out.view(cout, b, oh, ow).permute(1, 0, 2, 3).contiguous()
+        low = _autocast_dtype(x)
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            x, weight = _as_dtype(x, low), _as_dtype(weight, low)
+            b, _, h, w = x.shape
+            cout, _, kh, kw = weight.shape
+            cols = _patch_matrix(x, kh, kw, ph, pw)
+            ctx.save_for_backward(cols, weight)
+            ctx.geom = (b, h, w, ph, pw)
+            oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+            out = weight.reshape(cout, -1) @ cols  # [Cout, B*oh*ow]
+            return out.view(cout, b, oh, ow).permute(1, 0, 2, 3).contiguous()
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -106,22 +127,25 @@ class _ConvGemmCM(torch.autograd.Function):
     """
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x: torch.Tensor, weight: torch.Tensor, ph: int, pw: int) -> torch.Tensor:  # noqa: ANN001
         from ..ops import hip_learner
 
-        cin, b, h, w = x.shape
-        cout, _, kh, kw = weight.shape
-        if kh == 1 and kw == 1:
-            cols = x.reshape(cin, b * h * w)
-        elif x.is_cuda:
-            cols = hip_learner.patch_matrix_cm(x, kh, kw, ph, pw)
-        else:  # host tensors (tests of the channel-major plumbing): strided-view gather
-            cols = _patch_matrix(x.permute(1, 0, 2, 3), kh, kw, ph, pw)
-        ctx.save_for_backward(cols, weight)
-        ctx.geom = (b, h, w, ph, pw)
-        oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-        return (weight.reshape(cout, -1) @ cols).view(cout, b, oh, ow)
+        low = _autocast_dtype(x)
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            x, weight = _as_dtype(x, low), _as_dtype(weight, low)
+            cin, b, h, w = x.shape
+            cout, _, kh, kw = weight.shape
+            if kh == 1 and kw == 1:
+                cols = x.reshape(cin, b * h * w)
+            elif x.is_cuda:
+                cols = hip_learner.patch_matrix_cm(x, kh, kw, ph, pw)
+            else:  # host tensors (tests of the channel-major plumbing): strided-view gather
+                cols = _patch_matrix(x.permute(1, 0, 2, 3), kh, kw, ph, pw)
+            ctx.save_for_backward(cols, weight)
+            ctx.geom = (b, h, w, ph, pw)
+            oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+            return (weight.reshape(cout, -1) @ cols).view(cout, b, oh, ow)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -261,11 +285,14 @@ class _SplitKLinear(torch.autograd.Function):
     """
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:  # noqa: ANN001
-        ctx.save_for_backward(x2, weight)
-        ctx.has_bias = bias is not None
-        return torch.addmm(bias, x2, weight.t()) if bias is not None else x2 @ weight.t()
+        low = _autocast_dtype(x2)
+        with torch.autocast(device_type=x2.device.type, enabled=False):
+            x2, weight = _as_dtype(x2, low), _as_dtype(weight, low)
+            ctx.save_for_backward(x2, weight)
+            ctx.has_bias = bias is not None
+            return torch.addmm(_as_dtype(bias, low), x2, weight.t()) if bias is not None else x2 @ weight.t()
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")

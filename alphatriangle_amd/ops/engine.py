@@ -48,6 +48,7 @@ class GpuTreeEngine:
         logits: torch.Tensor,
         values: torch.Tensor,
         seed: int = 0,
+        compact: bool = False,
     ):
         hb.lib()
         self.env_config = env_config
@@ -88,6 +89,10 @@ class GpuTreeEngine:
         ).to(dev)
         self.root_states = torch.zeros(G, STATE_BYTES, dtype=torch.uint8, device=dev)
         self.census = torch.zeros(G, CENSUS_WIDTH, dtype=torch.int32, device=dev)
+        # batch compaction: a selecting wave writes the rows of the leaves that need an evaluation densely and counts them
+        self.compact = bool(compact)
+        self.slot_row = torch.zeros(G * L, dtype=torch.int32, device=dev) if self.compact else None
+        self.live = torch.zeros(1, dtype=torch.int32, device=dev) if self.compact else None
 
         tb = hb.TreeBufsC()
         for a in range(2):
@@ -107,6 +112,8 @@ class GpuTreeEngine:
         tb.nn_value = self.values.data_ptr()
         tb.order = self.order.data_ptr()
         tb.census = self.census.data_ptr()
+        tb.slot_row = self.slot_row.data_ptr() if self.slot_row is not None else 0
+        tb.live_cursor = self.live.data_ptr() if self.live is not None else 0
         tb.G, tb.C, tb.A, tb.L, tb.P = G, Cn, A, L, self.P
         tb.other_dim = self.other_dim
         tb.logit_stride = int(self.logits.stride(0))
@@ -153,6 +160,10 @@ class GpuTreeEngine:
         hb.call("atri_init_roots", self.geom.ref(), C.byref(self.tb), C.byref(self.sp), hb.ptr(self.noise_rng))
 
     def wave(self, consume: bool, select: bool) -> None:
+        """One simulation wave.  With compaction, ``self.live`` afterwards holds the number of dense feature rows
+        (= leaves that need an evaluation) this wave wrote; it is cleared by a fill kernel first (graph-safe)."""
+        if select and self.live is not None:
+            self.live.zero_()
         hb.call("atri_tree_wave", self.geom.ref(), C.byref(self.tb), C.byref(self.sp), hb.i32(1 if consume else 0), hb.i32(1 if select else 0))
 
     def census_totals(self) -> torch.Tensor:

@@ -78,6 +78,8 @@ class TreeBufsC(C.Structure):
         ("nn_value", VP),
         ("order", VP),
         ("census", VP),
+        ("slot_row", VP),
+        ("live_cursor", VP),
         ("G", C.c_int32),
         ("C", C.c_int32),
         ("A", C.c_int32),

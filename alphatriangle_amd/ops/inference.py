@@ -35,6 +35,7 @@ from __future__ import annotations
 
 import logging
 import math
+import threading
 from dataclasses import dataclass
 from typing import Any
 
@@ -46,6 +47,9 @@ from ..config.model_config import ModelConfig
 from . import hipbind as hb
 
 logger = logging.getLogger(__name__)
+
+# the live row count is host state of the kernel library between atri_set_live_count and the launches that pick it up
+_LIVE_LOCK = threading.Lock()
 
 ACT_IDS = {"none": 0, "ReLU": 1, "GELU": 2, "SiLU": 3, "Tanh": 4, "Sigmoid": 5}
 
@@ -546,11 +550,28 @@ class InferenceEngine:
         return self.logits[:B, : self.A], self.values[:B]
 
     @torch.no_grad()
-    def forward(self, grid: torch.Tensor, other: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    def forward(self, grid: torch.Tensor, other: torch.Tensor, live: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
         """``grid`` f32 [B, 1, H, W] (or [B, HW]), ``other`` f32 [B, Do] -> ``(logits [B, A], value [B])``.
 
-        The returned tensors are views of the engine's persistent output buffers.
+        The returned tensors are views of the engine's persistent output buffers.  ``live`` (int32 [1] on the device):
+        only rows ``0 .. live-1`` hold leaves; the batch kernels are launched for all ``B`` rows and every workgroup
+        beyond the live count ends at once, so a search wave that needs fewer evaluations costs less without any host
+        synchronisation (the count is read on the device, also when the launches are replayed from a HIP graph).
+        Kernels of the less common paths that do not read the count simply evaluate all rows.
         """
+        if live is None:
+            return self._forward_all(grid, other)
+        if live.dtype != torch.int32 or live.numel() != 1 or not live.is_cuda:
+            raise ValueError("live must be one int32 on the engine's device")
+        set_live = getattr(hb.lib(), "atri_set_live_count")
+        with _LIVE_LOCK:
+            set_live(hb.ptr(live))
+            try:
+                return self._forward_all(grid, other)
+            finally:
+                set_live(hb.VP(0))
+
+    def _forward_all(self, grid: torch.Tensor, other: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         if not self.loaded:
             raise RuntimeError("InferenceEngine.load_from_module has not been called")
         B = int(grid.shape[0])

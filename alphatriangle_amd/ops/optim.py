@@ -49,6 +49,30 @@ class FlatParameterSpace:
                 p.data = self.flat_param[off : off + n].view(p.shape)
                 p.grad = self.flat_grad[off : off + n].view(p.shape)
 
+    def refresh_shadow(self, dtype: torch.dtype = torch.bfloat16) -> None:
+        """Low-precision copy of every parameter in ONE cast kernel over the flat buffer.
+
+        Each parameter gets its view of the copy as ``p._atri_shadow``; the learner's GEMM-lowered layers
+        (``models/model.py``) take that view under autocast instead of casting their weight themselves, which replaces
+        one small cast kernel per weight and step (46 of them for the default network) by this single launch.  It is
+        called at the start of every autocast step, so whoever wrote the parameters in between (optimizer kernel,
+        checkpoint load, weight broadcast) is picked up.
+        """
+        shadow = getattr(self, "flat_shadow", None)
+        if shadow is None or shadow.dtype != dtype:
+            shadow = torch.empty(self.total, dtype=dtype, device=self.flat_param.device)
+            self.flat_shadow = shadow
+            for p, off in zip(self.params, self.offsets, strict=True):
+                p._atri_shadow = shadow[off : off + p.numel()].view(p.shape)
+        with torch.no_grad():
+            shadow.copy_(self.flat_param)
+
+    def drop_shadow(self) -> None:
+        self.flat_shadow = None
+        for p in self.params:
+            if hasattr(p, "_atri_shadow"):
+                del p._atri_shadow
+
     def rebind(self) -> None:
         """Re-attach views after something replaced ``p.data`` / ``p.grad`` (e.g. ``zero_grad(set_to_none=True)``)."""
         with torch.no_grad():

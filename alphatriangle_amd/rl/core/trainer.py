@@ -262,6 +262,8 @@ class Trainer:
         else:
             self.optimizer.zero_grad()
         if self.autocast_bf16:
+            if self.flat is not None:
+                self.flat.refresh_shadow(torch.bfloat16)  # one cast of the flat buffer instead of one per weight
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
                 policy_logits, value_logits = self.model(tb.grid, tb.other)
         else:

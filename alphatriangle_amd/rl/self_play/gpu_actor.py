@@ -68,9 +68,11 @@ class LeafEvaluator:
     logits: torch.Tensor
     values: torch.Tensor
     graph_safe = False
+    supports_live = False  # can skip rows beyond a device-side row count
     dtype = "fp32"
 
-    def forward(self, grid: torch.Tensor, other: torch.Tensor) -> None:
+    def forward(self, grid: torch.Tensor, other: torch.Tensor, live: torch.Tensor | None = None) -> None:
+        """Evaluate rows ``0 .. B-1`` (or ``0 .. live-1`` when a device row count is given and supported)."""
         raise NotImplementedError
 
     def refresh(self) -> None:
@@ -82,6 +84,7 @@ class EngineEvaluator(LeafEvaluator):
     """The hand-written HIP network (ops/inference.py)."""
 
     graph_safe = True
+    supports_live = True
 
     def __init__(self, nn: NeuralNetwork, batch: int):
         self.nn = nn
@@ -91,8 +94,8 @@ class EngineEvaluator(LeafEvaluator):
         self.values = self.engine.values
         self.dtype = getattr(self.engine, "dtype", "bf16")
 
-    def forward(self, grid: torch.Tensor, other: torch.Tensor) -> None:
-        self.engine.forward(grid, other)
+    def forward(self, grid: torch.Tensor, other: torch.Tensor, live: torch.Tensor | None = None) -> None:
+        self.engine.forward(grid, other, live)
 
     def refresh(self) -> None:
         self.nn.sync_inference_weights()
@@ -124,7 +127,7 @@ class ModuleEvaluator(LeafEvaluator):
         self.chunk = int(chunk)
 
     @torch.no_grad()
-    def forward(self, grid: torch.Tensor, other: torch.Tensor) -> None:
+    def forward(self, grid: torch.Tensor, other: torch.Tensor, live: torch.Tensor | None = None) -> None:  # noqa: ARG002 - all rows
         B = int(grid.shape[0])
         if self.planes is not None:
             self.planes[:B, 0] = grid.view(B, self.shape[1], self.shape[2])
@@ -184,9 +187,10 @@ class GpuSelfPlayActor:
         self.L = int(system_config.LEAVES_PER_TREE)
         self.B = self.G * self.L
         self.evaluator = evaluator if evaluator is not None else make_evaluator(nn, system_config, self.B)
+        self.compact = bool(getattr(system_config, "COMPACT_LEAF_BATCH", True)) and self.evaluator.supports_live
         self.tree = GpuTreeEngine(
             env_config, mcts_config, self.device, self.G, self.L, model_config.OTHER_NN_INPUT_FEATURES_DIM,
-            self.evaluator.logits, self.evaluator.values, seed=seed,
+            self.evaluator.logits, self.evaluator.values, seed=seed, compact=self.compact,
         )
         if system_config.TEMPERATURE_SWITCH_GAME_STEP is not None:
             switch = int(system_config.TEMPERATURE_SWITCH_GAME_STEP)
@@ -232,12 +236,12 @@ class GpuSelfPlayActor:
         self.current_trainer_step = int(trainer_step)
 
     # ------------------------------------------------------------------ one simulation wave
-    def _forward(self) -> None:
-        self.evaluator.forward(self._grid_view, self._other_view)
+    def _forward(self, live: torch.Tensor | None = None) -> None:
+        self.evaluator.forward(self._grid_view, self._other_view, live)
 
     def _steady_wave(self) -> None:
         self.tree.wave(consume=True, select=True)
-        self._forward()
+        self._forward(self.tree.live)  # with compaction: only the rows this wave wrote
 
     def _capture(self) -> None:
         """Capture the steady-state wave into a HIP graph.
@@ -270,7 +274,7 @@ class GpuSelfPlayActor:
         rng("selfplay/waves")
         waves = self.waves_per_move
         tree.wave(consume=False, select=True)
-        self._forward()
+        self._forward(tree.live)
         remaining = waves - 1
         if remaining > 0:
             if self._use_graph:

@@ -15,13 +15,13 @@ from alphatriangle_amd.env import GameState
 pytestmark = pytest.mark.gpu
 
 
-def _engine(env, mcts, games, leaves, other_dim=30):
+def _engine(env, mcts, games, leaves, other_dim=30, compact=False):
     from alphatriangle_amd.ops.engine import GpuTreeEngine
 
     dev = torch.device("cuda")
     logits = torch.zeros(games * leaves, env.ACTION_DIM, dtype=torch.float32, device=dev)
     values = torch.zeros(games * leaves, dtype=torch.float32, device=dev)
-    return GpuTreeEngine(env, mcts, dev, games, leaves, other_dim, logits, values, seed=1)
+    return GpuTreeEngine(env, mcts, dev, games, leaves, other_dim, logits, values, seed=1, compact=compact)
 
 
 def _packed(states):
@@ -80,13 +80,14 @@ class _SyntheticNet:
         return logits.astype(np.float32), values.astype(np.float32)
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("leaves,large", [(1, False), (3, False), (1, True)])
-def test_tree_search_equals_host_search(leaves, large):
+def test_tree_search_equals_host_search(leaves, large, compact):
     env = EnvConfig.large() if large else EnvConfig()  # the large board (756 actions) takes the strided edge-scan path
     sims = 48
     mcts = AlphaTriangleMCTSConfig(max_simulations=sims, max_depth=6, dirichlet_epsilon=0.0, mcts_batch_size=leaves)
     G = 6
-    eng = _engine(env, mcts, G, leaves)
+    eng = _engine(env, mcts, G, leaves, compact=compact)  # compact: leaves that need the network get dense rows
     net = _SyntheticNet(env.ROWS * env.COLS, 30, env.ACTION_DIM)
     H = native.host()
     games = []
@@ -111,6 +112,10 @@ def test_tree_search_equals_host_search(leaves, large):
     waves = (sims + leaves - 1) // leaves
     for w in range(waves):
         eng.wave(consume=w > 0, select=True)
+        if compact:  # the row counter equals the number of slots that asked for an evaluation, and rows are a permutation
+            kinds = eng.slot_kind.cpu().numpy()
+            rows = eng.slot_row.cpu().numpy()[kinds == 1]
+            assert int(eng.live.item()) == len(rows) and sorted(rows.tolist()) == list(range(len(rows)))
         device_eval()
     eng.wave(consume=True, select=False)
     dv = eng.root_visits().cpu().numpy()
@@ -182,6 +187,49 @@ def test_per_game_step_metrics_and_slot_census():
     assert int(pg["triangles_cleared_step"].sum()) == rep.triangles_cleared
     c = rep.slot_census
     assert sum(c.values()) == actor.G * actor.waves_per_move and c["expand"] > 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_compacted_leaf_batch_plays_the_same_games(dtype):
+    """COMPACT_LEAF_BATCH: the engine kernels skip the rows beyond the device-side live count.  Same seeds with and
+    without it must give the same moves, rewards and replay contents - also once terminal leaves thin the batch out."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.rl.core.device_buffer import DeviceReplayBuffer
+    from alphatriangle_amd.rl.self_play.gpu_actor import GpuSelfPlayActor
+
+    dev = torch.device("cuda")
+    env = EnvConfig(ROWS=5, COLS=6, PLAYABLE_RANGE_PER_ROW=[(0, 6)] * 5, NUM_SHAPE_SLOTS=2)  # small board: games end within a few moves
+    mc = ModelConfig(OTHER_NN_INPUT_FEATURES_DIM=8 * 2 + 6)
+    tc = TrainConfig(DEVICE="cuda", BUFFER_CAPACITY=20000, MIN_BUFFER_SIZE_TO_TRAIN=64, BATCH_SIZE=32, N_STEP_RETURNS=3, MAX_TRAINING_STEPS=1000)
+    mcts = AlphaTriangleMCTSConfig(max_simulations=24, max_depth=6)
+    runs = []
+    for compact in (False, True):
+        torch.manual_seed(3)
+        sc = SystemConfig(GAMES_PER_GPU=80, INFERENCE_DTYPE=dtype, COMPACT_LEAF_BATCH=compact)
+        net = NeuralNetwork(mc, env, tc, dev, inference_dtype=dtype)
+        assert net.engine is not None and net.engine.dtype == dtype
+        replay = DeviceReplayBuffer(tc, env, mc, dev, sc)
+        actor = GpuSelfPlayActor(env, mc, mcts, tc, sc, net, replay, dev, seed=11)
+        assert actor.compact == compact and (actor.tree.live is not None) == compact
+        reports = [actor.play_move() for _ in range(10)]
+        n = len(replay)
+        runs.append((reports, replay.policy[:n].clone(), replay.ret[:n].clone(), actor.tree.current_root_states().clone()))
+        thin = sum(r.slot_census["terminal"] + r.slot_census["none"] + r.slot_census.get("depth_cap", 0) for r in reports)
+        assert thin > 0, "the scenario has to contain waves with fewer live rows than games"
+    (ra, pa, va, sa), (rb, pb, vb, sb) = runs
+    for x, y in zip(ra, rb):  # per-game values: the move-level means are float atomics, i.e. order dependent in the last bit
+        assert np.array_equal(x.per_game["step_reward"], y.per_game["step_reward"])
+        assert np.array_equal(x.per_game["current_score"], y.per_game["current_score"])
+    assert [r.slot_census for r in ra] == [r.slot_census for r in rb]
+    assert torch.equal(sa, sb)
+
+    def canonical(policy, ret):  # replay rows are emitted through an atomic cursor: compare them as multisets
+        key = (policy.double() @ torch.linspace(1.0, 2.0, policy.shape[1], dtype=torch.float64, device=policy.device)) + ret.double() * 7.0
+        order = torch.argsort(key, stable=True)
+        return policy[order], ret[order]
+
+    (pa, va), (pb, vb) = canonical(pa, va), canonical(pb, vb)
+    assert torch.equal(pa, pb) and torch.equal(va, vb)
 
 
 @pytest.mark.parametrize("evaluator", ["engine-bf16", "engine-fp32", "module"])

@@ -492,3 +492,35 @@ def test_fused_attention_draws_a_new_mask_on_every_graph_replay():
         torch.cuda.synchronize()
         assert torch.equal(eager_ctx, ctx) and torch.equal(eager_dqkv, dqkv)
     assert len(set(seeds)) == 3, "every replay has to draw its own dropout seed"
+
+
+def test_bf16_shadow_follows_the_parameters_through_optimizer_steps_and_outside_writes():
+    """Autocast steps read one flat bf16 copy of the parameters (refreshed by one cast per step) instead of casting each
+    weight: the copy has to track the optimizer's updates and any write made behind the trainer's back."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.rl.core.trainer import TensorBatch, Trainer
+
+    torch.manual_seed(41)
+    dev = torch.device("cuda")
+    env, mc = EnvConfig(), ModelConfig()
+    tc = TrainConfig(DEVICE="cuda", BATCH_SIZE=32, COMPILE_MODEL=False)
+    net = NeuralNetwork(mc, env, tc, dev)
+    trainer = Trainer(net, tc, env, autocast_bf16=True)
+    assert trainer.flat is not None
+    B = 32
+    pol = torch.rand(B, env.ACTION_DIM, device=dev)
+    tb = TensorBatch(grid=torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float(), other=torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev),
+                     policy_target=pol / pol.sum(1, keepdim=True), returns=torch.empty(B, device=dev).uniform_(-3, 3), weights=torch.ones(B, device=dev),
+                     indices=torch.arange(B, device=dev))
+    before = trainer.flat.flat_param.clone()
+    trainer.train_step_tensors(tb)
+    assert not torch.equal(before, trainer.flat.flat_param)
+    conv_w = net._orig_model.conv_body[0][0].weight
+    off = trainer.flat.offsets[[id(p) for p in trainer.flat.params].index(id(conv_w))]
+    assert conv_w._atri_shadow.dtype == torch.bfloat16
+    assert torch.equal(conv_w._atri_shadow, before[off : off + conv_w.numel()].view(conv_w.shape).bfloat16())  # what the step started from
+    with torch.no_grad():
+        conv_w.mul_(0.5)  # an outside write (checkpoint load, weight broadcast, ...)
+    expect = conv_w.detach().clone().bfloat16()
+    trainer.train_step_tensors(tb)
+    assert torch.equal(conv_w._atri_shadow, expect), "the step has to start from the parameters as they are now"

@@ -33,7 +33,7 @@ def _randomise_norm_layers(model: torch.nn.Module) -> None:
 
 @pytest.mark.parametrize("preset,act", [("default", "ReLU"), ("cnn", "ReLU"), ("default", "GELU")])
 @pytest.mark.parametrize("batch", [37, 300])
-def test_fp32_engine_is_as_close_to_fp64_as_pytorch_fp32(preset, act, batch):
+def test_fp32_engine_stays_within_an_order_of_magnitude_of_pytorch_fp32_rounding(preset, act, batch):
     from alphatriangle_amd.models.network import NeuralNetwork
 
     torch.manual_seed(5)
@@ -64,10 +64,11 @@ def test_fp32_engine_is_as_close_to_fp64_as_pytorch_fp32(preset, act, batch):
     vt32 = (val32 - val64).abs().max().item()
     print(f"[{preset}/{act}/B={batch}] logits: engine {eng_err:.3e}, torch fp32 {t32_err:.3e} (scale {scale:.2f}); "
           f"value: engine {veng:.3e}, torch fp32 {vt32:.3e}")
-    # the engine's distance to the fp64 result is of the order of PyTorch fp32's own distance, four orders of magnitude
-    # below what the bf16 engine is allowed (0.05 * scale + 0.03 in tests/test_gpu_nn.py)
-    assert eng_err < 2e-4 * max(scale, 1.0), f"logit error {eng_err} vs fp64 (torch fp32: {t32_err})"
-    assert veng < 2e-4, f"value error {veng} vs fp64 (torch fp32: {vt32})"
+    # measured: engine 4 - 6e-6, PyTorch fp32 3 - 7e-7 (the (hi, lo) split keeps 16 significant bits per operand), three
+    # orders of magnitude below what the bf16 engine is allowed (0.05 * scale + 0.03 in tests/test_gpu_nn.py)
+    assert eng_err < 5e-5 * max(scale, 1.0), f"logit error {eng_err} vs fp64 (torch fp32: {t32_err})"
+    assert eng_err < 40 * max(t32_err, 2e-7), f"logit error {eng_err} is more than 40x PyTorch fp32's own ({t32_err})"
+    assert veng < 5e-5, f"value error {veng} vs fp64 (torch fp32: {vt32})"
     assert (logits.argmax(1) == ref64_l.argmax(1)).float().mean().item() >= 0.99
 
 
@@ -92,8 +93,8 @@ def test_fp32_engine_ignores_rows_beyond_the_batch_and_handles_small_boards():
             ref_val = net._logits_to_expected_value(ref_v).squeeze(1)
         logits, value = net.evaluate_features(grid, other)
         torch.cuda.synchronize()
-        assert (logits - ref_l).abs().max().item() < 3e-4 * max(1.0, ref_l.abs().max().item())
-        assert (value - ref_val).abs().max().item() < 3e-4
+        assert (logits - ref_l).abs().max().item() < 1e-4 * max(1.0, ref_l.abs().max().item())
+        assert (value - ref_val).abs().max().item() < 1e-4
 
 
 def _briefly_trained_network(dtype: str):
@@ -194,5 +195,5 @@ def test_search_picks_the_same_moves_under_bf16_fp32_engine_and_fp32_module():
     s16, kl16, klmax16 = compare(v16)
     print(f"fp32 engine vs fp32 module: same move {s32:.4f}, mean KL {kl32:.3e}, max KL {klmax32:.3e}")
     print(f"bf16 engine vs fp32 module: same move {s16:.4f}, mean KL {kl16:.3e}, max KL {klmax16:.3e}")
-    assert s32 >= 0.99 and kl32 < 5e-3
+    assert s32 >= 0.99 and kl32 < 1e-3
     assert s16 >= 0.95 and kl16 < 0.05
