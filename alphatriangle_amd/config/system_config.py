@@ -25,7 +25,7 @@ class SystemConfig(BaseModel):
     LEAVES_PER_TREE: int = Field(default=1, ge=1, le=32, description="Leaves per tree per wave (virtual loss if >1).")
     COMPACT_LEAF_BATCH: bool = Field(
         default=True,
-        description="Evaluate only the leaf slots that need the network: the tree kernel packs their feature rows densely and "
+        description="Evaluate only the leaf slots that need the network: their feature rows are written densely (slot scan) and "
         "the engine kernels read the row count on the device (no host sync).  Saves network time once games reach "
         "terminal states (about 10 % of the slots in steady state).",
     )
@@ -39,6 +39,12 @@ class SystemConfig(BaseModel):
     LEARNER_AUTOCAST: bool | None = Field(
         default=None,
         description="bf16 autocast for the learner forward/backward; None follows INFERENCE_DTYPE (off for fp32).",
+    )
+    LEARNER_FP32_GEMM: Literal["bf16x3", "library"] = Field(
+        default="bf16x3",
+        description="fp32 learner steps: 'bf16x3' runs the GEMM-lowered layers on the bf16 matrix cores (three passes over "
+        "(hi, lo) operand splits, ~5e-6 relative error per product - the scheme of the fp32-grade inference engine); "
+        "'library' keeps hipBLASLt's native-fp32 GEMMs (~7e-7, about 20 % slower per step).",
     )
     REPLAY_HBM_BUDGET_GB: float = Field(default=64.0, gt=0)
     TRAIN_STEPS_PER_MOVE: int = Field(default=1, ge=0, description="Learner steps interleaved per self-play move.")
@@ -67,6 +73,12 @@ class SystemConfig(BaseModel):
 
     def learner_autocast(self) -> bool:
         return self.INFERENCE_DTYPE == "bf16" if self.LEARNER_AUTOCAST is None else bool(self.LEARNER_AUTOCAST)
+
+    def apply_learner_gemm_mode(self) -> None:
+        """Select the fp32 GEMM path of the learner's GEMM-lowered layers for this process (models/model.py)."""
+        from ..models import model as model_mod
+
+        model_mod.FP32_GEMM_ON_BF16_CORES = self.LEARNER_FP32_GEMM == "bf16x3"
 
     @model_validator(mode="after")
     def _check(self) -> "SystemConfig":

@@ -46,11 +46,14 @@ struct TreeBufs {
   // per-tree counters, private to the tree's wave (plain read-modify-write, summed on the host once per move):
   // [0..3] leaf slots by kind (none / expand / terminal / depth cap), [4] network evaluations that were not finite
   int32_t* census;     // [G][kCensus]
-  // Batch compaction: with a row counter, a simulation wave writes the feature rows of the leaves that need an
-  // evaluation densely (row = counter++, one atomic per leaf) and remembers the row per slot; the counter's final value
-  // is the live row count of the network kernels that follow.  Without one (nullptr) a slot's row is the slot itself.
+  // Batch compaction: with a live-row counter (live_cursor != nullptr) the selecting wave only marks its slots; a scan
+  // over the slot kinds then numbers the slots that need an evaluation in slot order (leaf_rows_kernel: slot_row, live
+  // count) and leaf_features_kernel writes their feature rows densely.  The network kernels that follow read the count
+  // on the device.  Without a counter a slot's row is the slot itself and the wave writes the features directly.
+  // (One atomicAdd per leaf on a shared counter instead of the scan was measured first: 4096 same-address atomics
+  // serialise and cost ~110 us per wave.)
   int32_t* slot_row;     // [G*L]
-  int32_t* live_cursor;  // [1], zeroed by the caller before every selecting wave
+  int32_t* live_cursor;  // [1] number of dense rows written by the last selecting wave
   int32_t G, C, A, L, P, other_dim, logit_stride, pad;
 };
 constexpr int kCensus = 8;
@@ -588,17 +591,8 @@ __global__ void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int d
         }
         leaf = nn;
         kind = st.over ? kSlotTerminal : kSlotExpand;
-        if (kind == kSlotExpand) {
-          int row = slot;
-          if (tb.live_cursor != nullptr) {
-            if (lane == 0) {
-              row = atomicAdd(tb.live_cursor, 1);
-              tb.slot_row[slot] = row;
-            }
-            row = __shfl(row, 0, 64);
-          }
-          wave_features(g, st, tb.nn_grid + (size_t)row * g.cells, tb.nn_other + (size_t)row * tb.other_dim, tb.other_dim, lane);
-        }
+        if (kind == kSlotExpand && tb.live_cursor == nullptr)  // with compaction the features follow in leaf_features_kernel
+          wave_features(g, st, tb.nn_grid + (size_t)slot * g.cells, tb.nn_other + (size_t)slot * tb.other_dim, tb.other_dim, lane);
         __syncthreads();
         break;
       }
@@ -614,6 +608,39 @@ __global__ void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int d
     }
     __syncthreads();
   }
+}
+
+// Batch compaction, step 1: number the slots that need an evaluation in slot order.  One workgroup; every thread owns a
+// contiguous run of slots, the runs' counts go through an LDS scan.
+__global__ __launch_bounds__(1024) void leaf_rows_kernel(TreeBufs tb) {
+  __shared__ int sums[1024];
+  const int n = tb.G * tb.L, tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(tid * per, n), hi = min(lo + per, n);
+  int c = 0;
+  for (int i = lo; i < hi; ++i) c += tb.slot_kind[i] == kSlotExpand;
+  sums[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
+    const int v = tid >= off ? sums[tid - off] : 0;
+    __syncthreads();
+    sums[tid] += v;
+    __syncthreads();
+  }
+  int row = sums[tid] - c;
+  for (int i = lo; i < hi; ++i)
+    if (tb.slot_kind[i] == kSlotExpand) tb.slot_row[i] = row++;
+  if (tid == 1023) *tb.live_cursor = sums[1023];
+}
+
+// Batch compaction, step 2: feature rows of the numbered slots, one wave per slot.
+__global__ void leaf_features_kernel(GeomView g, TreeBufs tb) {
+  const int slot = blockIdx.x, lane = threadIdx.x;
+  if (tb.slot_kind[slot] != kSlotExpand) return;
+  const int t = slot / tb.L;
+  const State st = tree_states(tb, t)[tb.slot_leaf[slot]];
+  const int row = tb.slot_row[slot];
+  wave_features(g, st, tb.nn_grid + (size_t)row * g.cells, tb.nn_other + (size_t)row * tb.other_dim, tb.other_dim, lane);
 }
 
 // Root visit counts -> dense int32 [G][A] (for tests and host-side inspection).
@@ -1016,6 +1043,10 @@ int atri_tree_wave(const GeomView* g, const TreeBufs* tb, const SearchParams* sp
                    hipStream_t s) {
   if (sp->max_depth > tb->P) return -10;
   hipLaunchKernelGGL(tree_wave_kernel, dim3(tb->G), dim3(64), 0, s, *g, *tb, *sp, do_consume, do_select);
+  if (do_select && tb->live_cursor != nullptr) {
+    hipLaunchKernelGGL(leaf_rows_kernel, dim3(1), dim3(1024), 0, s, *tb);
+    hipLaunchKernelGGL(leaf_features_kernel, dim3(tb->G * tb->L), dim3(64), 0, s, *g, *tb);
+  }
   return (int)hipGetLastError();
 }
 int atri_root_visits(const TreeBufs* tb, int32_t* visits, hipStream_t s) {

@@ -44,6 +44,24 @@ def _as_dtype(weight: torch.Tensor, dtype: torch.dtype | None) -> torch.Tensor:
     return weight.to(dtype)
 
 
+# fp32 CUDA products of the GEMM-lowered layers run on the bf16 matrix cores (three passes over (hi, lo) operand splits,
+# ops.hip_learner.mm3) instead of the library's native-fp32 GEMMs; False restores the library path (A/B runs, tests).
+FP32_GEMM_ON_BF16_CORES = True
+
+
+def _mm(a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """``a @ b (+ bias)`` for 2-D or batched 3-D operands; fp32 CUDA operands go through :func:`ops.hip_learner.mm3`."""
+    if FP32_GEMM_ON_BF16_CORES and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32:
+        from ..ops import hip_learner
+
+        out = hip_learner.mm3(a, b, bias)
+        if out is not None:
+            return out
+    if bias is not None:
+        return torch.addmm(bias, a, b)
+    return torch.bmm(a, b) if a.dim() == 3 else a @ b
+
+
 def _split_count(n: int, limit: int = 32, min_chunk: int = 512) -> int:
     """Largest divisor of ``n`` that is at most ``limit`` and leaves chunks of at least ``min_chunk``."""
     for s in range(min(limit, max(1, n // min_chunk)), 1, -1):
@@ -145,7 +163,7 @@ class _ConvGemmCM(torch.autograd.Function):
             ctx.save_for_backward(cols, weight)
             ctx.geom = (b, h, w, ph, pw)
             oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-            return (weight.reshape(cout, -1) @ cols).view(cout, b, oh, ow)
+            return _mm(weight.reshape(cout, -1), cols).view(cout, b, oh, ow)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -161,18 +179,18 @@ class _ConvGemmCM(torch.autograd.Function):
             k, n = cols.shape
             g2 = g.view(cout, n)
             s = _split_count(n)
-            parts = torch.bmm(g2.view(cout, s, n // s).transpose(0, 1), cols.view(k, s, n // s).permute(1, 2, 0))
+            parts = _mm(g2.view(cout, s, n // s).transpose(0, 1), cols.view(k, s, n // s).permute(1, 2, 0))
             d_w = parts.sum(0, dtype=_grad_dtype(parts)).view(cout, cin, kh, kw)
         if ctx.needs_input_grad[0]:
             if kh == 1 and kw == 1:
-                d_x = (weight.reshape(cout, cin).t() @ g.view(cout, -1)).view(cin, b, h, w)
+                d_x = _mm(weight.reshape(cout, cin).t(), g.view(cout, -1)).view(cin, b, h, w)
             else:
                 if g.is_cuda:
                     g_cols = hip_learner.patch_matrix_cm(g, kh, kw, kh - 1 - ph, kw - 1 - pw)  # [Cout*kh*kw, B*H*W]
                 else:
                     g_cols = _patch_matrix(g.permute(1, 0, 2, 3), kh, kw, kh - 1 - ph, kw - 1 - pw)
                 w_t = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * kh * kw)
-                d_x = (w_t @ g_cols).view(cin, b, h, w)
+                d_x = _mm(w_t, g_cols).view(cin, b, h, w)
         return d_x, d_w, None, None
 
 
@@ -292,7 +310,7 @@ class _SplitKLinear(torch.autograd.Function):
             x2, weight = _as_dtype(x2, low), _as_dtype(weight, low)
             ctx.save_for_backward(x2, weight)
             ctx.has_bias = bias is not None
-            return torch.addmm(_as_dtype(bias, low), x2, weight.t()) if bias is not None else x2 @ weight.t()
+            return _mm(x2, weight.t(), _as_dtype(bias, low) if bias is not None else None)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -302,10 +320,10 @@ class _SplitKLinear(torch.autograd.Function):
         n, out_f = g.shape
         s = _split_count(n)
         gs = g.view(s, n // s, out_f)
-        d_x = g @ weight if ctx.needs_input_grad[0] else None
+        d_x = _mm(g, weight) if ctx.needs_input_grad[0] else None
         d_w = None
         if ctx.needs_input_grad[1]:
-            parts = torch.bmm(gs.transpose(1, 2), x2.reshape(s, n // s, x2.shape[1]))
+            parts = _mm(gs.transpose(1, 2), x2.reshape(s, n // s, x2.shape[1]))
             d_w = parts.sum(0, dtype=_grad_dtype(parts))
         d_b = None
         if ctx.has_bias and ctx.needs_input_grad[2]:

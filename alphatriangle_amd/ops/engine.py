@@ -160,10 +160,8 @@ class GpuTreeEngine:
         hb.call("atri_init_roots", self.geom.ref(), C.byref(self.tb), C.byref(self.sp), hb.ptr(self.noise_rng))
 
     def wave(self, consume: bool, select: bool) -> None:
-        """One simulation wave.  With compaction, ``self.live`` afterwards holds the number of dense feature rows
-        (= leaves that need an evaluation) this wave wrote; it is cleared by a fill kernel first (graph-safe)."""
-        if select and self.live is not None:
-            self.live.zero_()
+        """One simulation wave.  With compaction, a selecting wave is followed by the slot scan and the feature kernel
+        (same launch call); ``self.live`` then holds the number of dense feature rows = leaves that need an evaluation."""
         hb.call("atri_tree_wave", self.geom.ref(), C.byref(self.tb), C.byref(self.sp), hb.i32(1 if consume else 0), hb.i32(1 if select else 0))
 
     def census_totals(self) -> torch.Tensor:

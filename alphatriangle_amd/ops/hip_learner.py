@@ -204,6 +204,55 @@ def bn_act_cm_backward(x: torch.Tensor, residual: torch.Tensor | None, dy: torch
     return dx, dr, dgamma, dbeta
 
 
+# ---------------------------------------------------------------- fp32 GEMM on the bf16 matrix cores (three passes)
+def _gemm3_layout(t: torch.Tensor) -> tuple[int, int] | None:
+    """(row stride, column stride) of the last two dimensions when one of them is 1 and the other a multiple of 4."""
+    sr, sc = int(t.stride(-2)), int(t.stride(-1))
+    if t.shape[-1] == 1:
+        sc = 1 if sr != 1 else sc
+    if t.shape[-2] == 1:
+        sr = 1 if sc != 1 else sr
+    if sc == 1 and sr % 4 == 0 and sr >= t.shape[-1]:
+        return sr, 1
+    if sr == 1 and sc % 4 == 0 and sc >= t.shape[-2]:
+        return 1, sc
+    return None
+
+
+def mm3(a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor | None:
+    """``a @ b (+ bias)`` for fp32 CUDA operands through ``gemm3_kernel`` (fp32-grade: three bf16 MFMA passes over (hi, lo)
+    splits), or ``None`` when the operands do not fit it (the caller then uses the library GEMM).
+
+    ``a`` is ``[M, K]`` or ``[S, M, K]``, ``b`` is ``[K, N]`` or ``[S, K, N]`` (batched for split-K weight gradients); either
+    dimension of each matrix may be the contiguous one, so transposed views need no copy.
+    """
+    if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == b.dim() and a.dim() in (2, 3) and available()):
+        return None
+    batch = int(a.shape[0]) if a.dim() == 3 else 1
+    if a.dim() == 3 and (b.shape[0] != batch or batch > 65535):
+        return None
+    m, k = int(a.shape[-2]), int(a.shape[-1])
+    n = int(b.shape[-1])
+    if int(b.shape[-2]) != k or n % 4 or min(m, n, k) < 1:
+        return None
+    la, lb = _gemm3_layout(a), _gemm3_layout(b)
+    if la is None or lb is None:
+        return None
+    a_kc, b_kc = la[1] == 1, lb[0] == 1
+    if (a_kc and k % 4) or (not a_kc and m % 4) or (b_kc and k % 4):
+        return None
+    a_bs = int(a.stride(0)) if a.dim() == 3 else 0
+    b_bs = int(b.stride(0)) if b.dim() == 3 else 0
+    if a_bs % 4 or b_bs % 4 or a.data_ptr() % 16 or b.data_ptr() % 16:
+        return None
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != n or not bias.is_contiguous() or bias.data_ptr() % 16):
+        return None
+    out = torch.empty((batch, m, n) if a.dim() == 3 else (m, n), dtype=torch.float32, device=a.device)
+    hb.call("atri_gemm3", hb.ptr(a), hb.ptr(b), hb.ptr(out), hb.ptr(bias), hb.i32(m), hb.i32(n), hb.i32(k), hb.i64(la[0]), hb.i64(la[1]),
+            hb.i64(lb[0]), hb.i64(lb[1]), hb.i64(n), hb.i32(batch), hb.i64(a_bs), hb.i64(b_bs), hb.i64(m * n))
+    return out
+
+
 # ---------------------------------------------------------------- fused multi-head self-attention (32-wide heads)
 def attention_supported(qkv: torch.Tensor, heads: int) -> bool:
     """True when :func:`attention_forward` handles packed ``qkv [L, B, 3 * 32 * heads]`` (bf16 or f32, up to 256 tokens)."""

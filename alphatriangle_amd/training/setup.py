@@ -149,6 +149,7 @@ def setup_training_components(
             if dist_context is not None and dist_context.world_size > 1:
                 n_sync = dist_context.num_learners if split else dist_context.world_size
                 grad_sync = dist_context.grad_sync if n_sync > 1 else None
+            system_config.apply_learner_gemm_mode()
             trainer = Trainer(
                 neural_net,
                 train_config,
