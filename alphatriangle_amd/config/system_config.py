@@ -46,6 +46,11 @@ class SystemConfig(BaseModel):
         "(hi, lo) operand splits, ~5e-6 relative error per product - the scheme of the fp32-grade inference engine); "
         "'library' keeps hipBLASLt's native-fp32 GEMMs (~7e-7, about 20 % slower per step).",
     )
+    LEARNER_PATCH_FREE_CONV: bool = Field(
+        default=False,
+        description="fp32 'bf16x3' learner steps: generate the 3x3 patches inside the GEMM instead of storing a patch matrix per "
+        "layer (9x less activation memory for the backward pass, slower products).",
+    )
     REPLAY_HBM_BUDGET_GB: float = Field(default=64.0, gt=0)
     TRAIN_STEPS_PER_MOVE: int = Field(default=1, ge=0, description="Learner steps interleaved per self-play move.")
     TRAIN_STEPS_PER_ROUND: int = Field(
@@ -79,6 +84,7 @@ class SystemConfig(BaseModel):
         from ..models import model as model_mod
 
         model_mod.FP32_GEMM_ON_BF16_CORES = self.LEARNER_FP32_GEMM == "bf16x3"
+        model_mod.PATCH_FREE_CONV = bool(self.LEARNER_PATCH_FREE_CONV)
 
     @model_validator(mode="after")
     def _check(self) -> "SystemConfig":

@@ -10,6 +10,8 @@
 // whose 16-byte chunks are XOR-swizzled by the row (conflict-free ds_read_b128 without padding).  Loads of step k + 1
 // are in flight while step k is multiplied (register staging, two LDS buffers).  A batch dimension (grid z) with
 // element strides serves split-K weight gradients.
+#include <type_traits>
+
 #include "common.hpp"
 
 using namespace atrihip;
@@ -24,6 +26,11 @@ struct Gemm3Args {
   long long ldc;           // C(m, n) = C[m * ldc + n]
   long long a_batch, b_batch, c_batch;
   int M, N, K;
+  // B_MODE 2 / 3: B is the patch matrix of a 3x3, padding-1 convolution over the channel-major activation B = x[cin][nb][h][w],
+  // generated while loading (never in memory): patch row (ci, ky, kx) = ci * 9 + ky * 3 + kx, patch column = position
+  // (b * h + y) * w + x.  Mode 2: B(k, n) = patch[k][n] (forward / data gradient, N = positions).  Mode 3:
+  // B(k, n) = patch[n][k_off + k] (weight gradient, K = a chunk of positions starting at k_off = blockIdx.z * b_batch).
+  int cin, nb, h, w;
 };
 
 namespace {
@@ -103,6 +110,126 @@ struct TileLoader {
   }
 };
 
+__device__ __forceinline__ void div_small(int n, int d, float inv, int& q, int& r) {  // n < 2^24, d > 0
+  q = (int)((float)n * inv);
+  r = n - q * d;
+  if (r < 0) {
+    --q;
+    r += d;
+  } else if (r >= d) {
+    ++q;
+    r -= d;
+  }
+}
+
+// Patch-matrix tile with the positions as tile rows (B_MODE 2).  A thread holds a 4 x 4 block: k = 4 kq .. + 3 and the
+// four positions n0 + rq + 32 j (consecutive lanes read consecutive positions: coalesced 4-byte loads).  Its positions are
+// fixed for the whole kernel, so which of the nine taps fall inside the board is decided once (one bit per tap).
+// Loads are unconditional from a clamped index and masked afterwards (no divergent branches).  Two aligned 16-byte loads
+// plus a select per four values instead of four 4-byte loads measured 25 % slower (more arithmetic per value).
+struct PatchRowsLoader {
+  float v[4][4];  // [k][position]
+  int n[4];
+  unsigned taps[4];
+  __device__ __forceinline__ void init(const Gemm3Args& g, int n0, int tid) {
+    const int rq = tid & 31, hw = g.h * g.w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      n[j] = n0 + rq + 32 * j;
+      const int p = n[j] % hw, y = p / g.w, x = p % g.w;
+      unsigned m = 0;
+      if (n[j] < g.N) {
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+          if (yy >= 0 && yy < g.h && xx >= 0 && xx < g.w) m |= 1u << tp;
+        }
+      }
+      taps[j] = m;
+    }
+  }
+  __device__ __forceinline__ void load(const Gemm3Args& g, const float* X, int k0, int tid) {
+    const int kq = tid >> 5;
+    const int plane = g.nb * g.h * g.w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + kq * 4 + i;
+      const int ci = k / 9, tp = k - ci * 9, ky = tp / 3, kx = tp - ky * 3;
+      const int off = ci * plane + (ky - 1) * g.w + (kx - 1);
+      const unsigned bit = k < g.K ? 1u << tp : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = (taps[j] & bit) != 0;  // ok implies 0 <= off + n[j] < cin * plane
+        const float val = X[ok ? off + n[j] : 0];
+        v[i][j] = ok ? val : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* tile, int tid) const {
+    const int kq = tid >> 5, rq = tid & 31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = rq + 32 * j;
+      uint2 hi, lo;
+      split4(make_float4(v[0][j], v[1][j], v[2][j], v[3][j]), hi, lo);
+      unsigned char* p = tile + r * kRowBytes + (((kq >> 1) ^ swz(r)) << 4) + ((kq & 1) << 3);
+      *reinterpret_cast<uint2*>(p) = hi;
+      *reinterpret_cast<uint2*>(p + kBN * kRowBytes) = lo;
+    }
+  }
+};
+
+// Patch-matrix tile with the patch rows (ci, ky, kx) as tile rows and positions along k (B_MODE 3): the register layout
+// of TileLoader<128, true> - float4s over four consecutive positions.  A thread's four patch rows are fixed for the
+// whole kernel; its four positions of a step are decoded once and shared by the four rows.
+struct PatchColsLoader {
+  TileLoader<kBN, true> t;
+  int roff[4];
+  int dy[4], dx[4];
+  float inv_hw, inv_w;
+  __device__ __forceinline__ void init(const Gemm3Args& g, int n0, int tid) {
+    const int plane = g.nb * g.h * g.w;
+    inv_hw = 1.0f / (float)(g.h * g.w);
+    inv_w = 1.0f / (float)g.w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = n0 + ((tid + i * 256) >> 3);
+      const int ci = row / 9, r = row - ci * 9, ky = r / 3, kx = r - ky * 3;
+      dy[i] = row < g.N ? ky - 1 : 1 << 20;  // a patch row beyond the matrix fails every bounds test below
+      dx[i] = kx - 1;
+      roff[i] = ci * plane + (ky - 1) * g.w + (kx - 1);
+    }
+  }
+  __device__ __forceinline__ void load(const Gemm3Args& g, const float* X, int k_off, int k0, int tid) {
+    const int kl = k0 + (tid & 7) * 4;  // first of this thread's four positions, relative to the chunk
+    int b, p, y, x;
+    div_small(k_off + kl, g.h * g.w, inv_hw, b, p);
+    div_small(p, g.w, inv_w, y, x);
+    int ys[4], xs[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ys[e] = kl + e < g.K ? y : -(1 << 21);
+      xs[e] = x;
+      if (++x == g.w) {
+        x = 0;
+        if (++y == g.h) y = 0;
+      }
+    }
+    const int pos = k_off + kl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float f[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // ok implies a source inside the same board, i.e. inside the tensor
+        const bool ok = (unsigned)(ys[e] + dy[i]) < (unsigned)g.h && (unsigned)(xs[e] + dx[i]) < (unsigned)g.w;
+        const float val = X[ok ? pos + roff[i] + e : 0];
+        f[e] = ok ? val : 0.f;
+      }
+      t.v[i] = make_float4(f[0], f[1], f[2], f[3]);
+    }
+  }
+};
+
 // MFMA fragment (hi, lo) of tile row `r` (16 rows per MFMA tile, lane l15 = row), k-chunk q4
 template <int ROWS>
 __device__ __forceinline__ void read_frag(const unsigned char* tile, int r, int q4, short8& hi, short8& lo) {
@@ -113,7 +240,8 @@ __device__ __forceinline__ void read_frag(const unsigned char* tile, int r, int 
 }  // namespace
 
 // MTW = MFMA row tiles per wave (4 / 2 / 1): BM = 32 * MTW rows of C per workgroup, waves arranged 2 (rows) x 2 (columns)
-template <int MTW, bool A_KCONTIG, bool B_KCONTIG>
+// B_MODE: 0 = B with n contiguous, 1 = B with k contiguous, 2 / 3 = patch matrix generated on the fly (Gemm3Args)
+template <int MTW, bool A_KCONTIG, int B_MODE>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Args g) {
   constexpr int BM = 32 * MTW;
   constexpr int kATile = 2 * BM * kRowBytes;   // hi + lo planes
@@ -124,13 +252,39 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Args g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * kBN;
   const float* A = g.A + (long long)blockIdx.z * g.a_batch;
-  const float* B = g.B + (long long)blockIdx.z * g.b_batch;
+  const float* B = B_MODE < 2 ? g.B + (long long)blockIdx.z * g.b_batch : g.B;
   float* C = g.C + (long long)blockIdx.z * g.c_batch;
 
-  TileLoader<BM, A_KCONTIG> la;
-  TileLoader<kBN, B_KCONTIG> lb;  // B tile rows are the n index
+  // Two register staging sets per operand: the loads of step s + 2 are issued before step s is multiplied and stored to
+  // LDS after step s + 1 was, so a load has two steps (about 2 x 770 matrix-pipe cycles per wave) to come back.
+  struct PlainB {
+    TileLoader<kBN, B_MODE == 1> t;
+  };
+  using BLoader = typename std::conditional<B_MODE == 2, PatchRowsLoader, typename std::conditional<B_MODE == 3, PatchColsLoader, PlainB>::type>::type;
+  TileLoader<BM, A_KCONTIG> la[2];
+  BLoader lb[2];  // B tile rows are the n index
+  if constexpr (B_MODE >= 2) {
+    lb[0].init(g, n0, tid);
+    lb[1] = lb[0];
+  }
+  const int k_off = B_MODE == 3 ? (int)(blockIdx.z * g.b_batch) : 0;
   // operand strides in the loader's terms: rows = m (A) / n (B)
   const long long a_row = g.a_row, a_k = g.a_k, b_row = g.b_col, b_k = g.b_k;
+  auto load = [&](auto P, int k0) {
+    constexpr int p = decltype(P)::value;
+    la[p].load(A, a_row, a_k, m0, g.M, k0, g.K, tid);
+    if constexpr (B_MODE == 2) lb[p].load(g, B, k0, tid);
+    else if constexpr (B_MODE == 3) lb[p].load(g, B, k_off, k0, tid);
+    else lb[p].t.load(B, b_row, b_k, n0, g.N, k0, g.K, tid);
+  };
+  auto store = [&](auto P, unsigned char* buf) {
+    constexpr int p = decltype(P)::value;
+    la[p].store(buf, tid);
+    if constexpr (B_MODE == 2) lb[p].store(buf + kATile, tid);
+    else lb[p].t.store(buf + kATile, tid);
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
 
   float4v acc[MTW][4];
 #pragma unroll
@@ -139,18 +293,17 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Args g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
 
   const int steps = (g.K + kBK - 1) / kBK;
-  la.load(A, a_row, a_k, m0, g.M, 0, g.K, tid);
-  lb.load(B, b_row, b_k, n0, g.N, 0, g.K, tid);
-  la.store(smem, tid);
-  lb.store(smem + kATile, tid);
+  load(P0{}, 0);
+  store(P0{}, smem);
+  if (steps > 1) load(P1{}, kBK);
   __syncthreads();
-  for (int s = 0; s < steps; ++s) {
-    const unsigned char* at = smem + (s & 1) * (kATile + kBTile);
+  // step s: LDS buffer s & 1 holds its operands, staging set (s + 1) & 1 holds (in flight) those of step s + 1
+  auto step = [&](auto P, int s) {
+    constexpr int p = decltype(P)::value;
+    using Other = std::integral_constant<int, 1 - p>;
+    const unsigned char* at = smem + p * (kATile + kBTile);
     const unsigned char* bt = at + kATile;
-    if (s + 1 < steps) {
-      la.load(A, a_row, a_k, m0, g.M, (s + 1) * kBK, g.K, tid);
-      lb.load(B, b_row, b_k, n0, g.N, (s + 1) * kBK, g.K, tid);
-    }
+    if (s + 2 < steps) load(P, (s + 2) * kBK);  // set p is free: step s went to LDS before step s - 1 was multiplied
     short8 ah[MTW], al[MTW], bh[4], bl[4];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) read_frag<BM>(at, (wm * MTW + i) * 16 + l15, q4, ah[i], al[i]);
@@ -160,12 +313,12 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Args g) {
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = mfma_split(bh[j], bl[j], ah[i], al[i], acc[i][j]);  // rows = n, columns = m
-    if (s + 1 < steps) {
-      unsigned char* nt = smem + ((s + 1) & 1) * (kATile + kBTile);
-      la.store(nt, tid);
-      lb.store(nt + kATile, tid);
-    }
+    if (s + 1 < steps) store(Other{}, smem + (1 - p) * (kATile + kBTile));
     __syncthreads();
+  };
+  for (int s = 0; s < steps; s += 2) {
+    step(P0{}, s);
+    if (s + 1 < steps) step(P1{}, s + 1);
   }
 
   // acc[i][j][e] = C(m = m0 + (wm * MTW + i) * 16 + l15, n = n0 + (wn * 4 + j) * 16 + 4 q4 + e)
@@ -189,13 +342,23 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Args g) {
 
 namespace {
 template <int MTW>
-int launch_gemm3(const Gemm3Args& g, int batch, bool a_kc, bool b_kc, hipStream_t stream) {
+int launch_gemm3(const Gemm3Args& g, int batch, bool a_kc, int b_mode, hipStream_t stream) {
   const dim3 grid((g.N + kBN - 1) / kBN, (g.M + 32 * MTW - 1) / (32 * MTW), batch);
-  if (a_kc && b_kc) hipLaunchKernelGGL((gemm3_kernel<MTW, true, true>), grid, dim3(256), 0, stream, g);
-  else if (a_kc) hipLaunchKernelGGL((gemm3_kernel<MTW, true, false>), grid, dim3(256), 0, stream, g);
-  else if (b_kc) hipLaunchKernelGGL((gemm3_kernel<MTW, false, true>), grid, dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((gemm3_kernel<MTW, false, false>), grid, dim3(256), 0, stream, g);
+  switch ((a_kc ? 4 : 0) + b_mode) {
+    case 0: hipLaunchKernelGGL((gemm3_kernel<MTW, false, 0>), grid, dim3(256), 0, stream, g); break;
+    case 1: hipLaunchKernelGGL((gemm3_kernel<MTW, false, 1>), grid, dim3(256), 0, stream, g); break;
+    case 4: hipLaunchKernelGGL((gemm3_kernel<MTW, true, 0>), grid, dim3(256), 0, stream, g); break;
+    case 5: hipLaunchKernelGGL((gemm3_kernel<MTW, true, 1>), grid, dim3(256), 0, stream, g); break;
+    case 6: hipLaunchKernelGGL((gemm3_kernel<MTW, true, 2>), grid, dim3(256), 0, stream, g); break;
+    case 7: hipLaunchKernelGGL((gemm3_kernel<MTW, true, 3>), grid, dim3(256), 0, stream, g); break;
+    default: return -15;
+  }
   return hip_err(hipGetLastError());
+}
+int launch_for_m(const Gemm3Args& g, int batch, bool a_kc, int b_mode, hipStream_t stream) {
+  if (g.M > 64) return launch_gemm3<4>(g, batch, a_kc, b_mode, stream);
+  if (g.M > 32) return launch_gemm3<2>(g, batch, a_kc, b_mode, stream);
+  return launch_gemm3<1>(g, batch, a_kc, b_mode, stream);
 }
 }  // namespace
 
@@ -217,10 +380,35 @@ int atri_gemm3(const float* A, const float* B, float* C, const float* bias, int 
   if (!a_kc && (M & 3)) return -13;  // float4 along m
   if (b_kc && (K & 3)) return -13;
   if (batch > 65535) return -14;
-  Gemm3Args g{A, B, C, bias, a_row, a_k, b_k, b_col, ldc, a_batch, b_batch, c_batch, M, N, K};
-  if (M > 64) return launch_gemm3<4>(g, batch, a_kc, b_kc, stream);
-  if (M > 32) return launch_gemm3<2>(g, batch, a_kc, b_kc, stream);
-  return launch_gemm3<1>(g, batch, a_kc, b_kc, stream);
+  Gemm3Args g{A, B, C, bias, a_row, a_k, b_k, b_col, ldc, a_batch, b_batch, c_batch, M, N, K, 0, 0, 0, 0};
+  return launch_for_m(g, batch, a_kc, b_kc ? 1 : 0, stream);
+}
+
+// 3x3, padding-1 convolution products over a channel-major activation X = x[cin][nb][h][w] without a patch matrix in
+// memory (A row-major [M, K], fp32 in / out, three-pass bf16 MFMA):
+//   transposed = 0: C[M, nb*h*w] = A[M, cin*9] patches(X)                       (forward; data gradient with flipped weights)
+//   transposed = 1: C[z][M, cin*9] = A[:, z*chunk : (z+1)*chunk] patches(X)[:, same]^T for z < positions / chunk
+//                   (split-K weight gradient; the caller adds the z slices)
+// cin and chunk must be multiples of 4, nb*h*w a multiple of 4 (and of chunk when transposed).
+int atri_conv3_gemm(const float* A, const float* X, float* C, int M, int cin, int nb, int h, int w, long long lda, int transposed,
+                    int chunk, hipStream_t stream) {
+  const long long positions = (long long)nb * h * w;
+  if (M <= 0 || cin <= 0 || positions <= 0) return 0;
+  if ((cin & 3) || (positions & 3) || (lda & 3) || positions >= (1 << 24) || h < 1 || w < 1) return -20;
+  if ((long long)cin * positions >= (1LL << 31)) return -20;  // 32-bit element offsets inside the loaders
+  if (((uintptr_t)A | (uintptr_t)X | (uintptr_t)C) & 15) return -21;
+  Gemm3Args g{};
+  g.A = A; g.B = X; g.C = C; g.bias = nullptr;
+  g.a_row = lda; g.a_k = 1;
+  g.M = M; g.cin = cin; g.nb = nb; g.h = h; g.w = w;
+  if (!transposed) {
+    g.N = (int)positions; g.K = cin * 9; g.ldc = positions;
+    return launch_for_m(g, 1, true, 2, stream);
+  }
+  if (chunk <= 0 || (chunk & 3) || positions % chunk != 0 || positions / chunk > 65535) return -22;
+  g.N = cin * 9; g.K = chunk; g.ldc = g.N;
+  g.a_batch = chunk; g.b_batch = chunk; g.c_batch = (long long)M * g.N;
+  return launch_for_m(g, (int)(positions / chunk), true, 3, stream);
 }
 
 }  // extern "C"

@@ -47,6 +47,11 @@ def _as_dtype(weight: torch.Tensor, dtype: torch.dtype | None) -> torch.Tensor:
 # fp32 CUDA products of the GEMM-lowered layers run on the bf16 matrix cores (three passes over (hi, lo) operand splits,
 # ops.hip_learner.mm3) instead of the library's native-fp32 GEMMs; False restores the library path (A/B runs, tests).
 FP32_GEMM_ON_BF16_CORES = True
+# 3x3 convolutions of the fp32 path without a patch matrix in memory (ops.hip_learner.conv3_mm / conv3_wgrad: the GEMM's
+# operand loader generates the patches): nine times less activation memory per layer kept for the backward pass, about
+# 75 % slower products (the loader's per-value address and bounds arithmetic costs more than the patch traffic it saves;
+# the plain products already run at the speed their patch matrix can be read at).  SystemConfig.LEARNER_PATCH_FREE_CONV.
+PATCH_FREE_CONV = False
 
 
 def _mm(a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
@@ -154,6 +159,16 @@ class _ConvGemmCM(torch.autograd.Function):
             x, weight = _as_dtype(x, low), _as_dtype(weight, low)
             cin, b, h, w = x.shape
             cout, _, kh, kw = weight.shape
+            oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+            ctx.geom = (b, h, w, ph, pw)
+            x = x.contiguous()
+            w2 = weight.reshape(cout, -1)
+            # fp32 3x3 / padding-1 layers: the patch matrix is generated inside the GEMM's loader and never stored
+            ctx.implicit = bool(FP32_GEMM_ON_BF16_CORES and PATCH_FREE_CONV and (kh, kw, ph, pw) == (3, 3, 1, 1) and x.is_cuda
+                                and hip_learner.conv3_supported(x, w2))
+            if ctx.implicit:
+                ctx.save_for_backward(x, weight)
+                return hip_learner.conv3_mm(w2, x).view(cout, b, oh, ow)
             if kh == 1 and kw == 1:
                 cols = x.reshape(cin, b * h * w)
             elif x.is_cuda:
@@ -161,36 +176,41 @@ class _ConvGemmCM(torch.autograd.Function):
             else:  # host tensors (tests of the channel-major plumbing): strided-view gather
                 cols = _patch_matrix(x.permute(1, 0, 2, 3), kh, kw, ph, pw)
             ctx.save_for_backward(cols, weight)
-            ctx.geom = (b, h, w, ph, pw)
-            oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-            return _mm(weight.reshape(cout, -1), cols).view(cout, b, oh, ow)
+            return _mm(w2, cols).view(cout, b, oh, ow)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
         from ..ops import hip_learner
 
-        cols, weight = ctx.saved_tensors
+        cols, weight = ctx.saved_tensors  # with ctx.implicit, `cols` is the layer input itself
         b, h, w, ph, pw = ctx.geom
         cout, cin, kh, kw = weight.shape
         g = grad_out.contiguous()
         d_x = d_w = None
         if ctx.needs_input_grad[1]:
-            k, n = cols.shape
+            n = b * h * w if ctx.implicit else cols.shape[1]
             g2 = g.view(cout, n)
             s = _split_count(n)
-            parts = _mm(g2.view(cout, s, n // s).transpose(0, 1), cols.view(k, s, n // s).permute(1, 2, 0))
+            if ctx.implicit:
+                parts = hip_learner.conv3_wgrad(g2, cols, n // s)
+            else:
+                k = cols.shape[0]
+                parts = _mm(g2.view(cout, s, n // s).transpose(0, 1), cols.view(k, s, n // s).permute(1, 2, 0))
             d_w = parts.sum(0, dtype=_grad_dtype(parts)).view(cout, cin, kh, kw)
         if ctx.needs_input_grad[0]:
             if kh == 1 and kw == 1:
                 d_x = _mm(weight.reshape(cout, cin).t(), g.view(cout, -1)).view(cin, b, h, w)
             else:
-                if g.is_cuda:
-                    g_cols = hip_learner.patch_matrix_cm(g, kh, kw, kh - 1 - ph, kw - 1 - pw)  # [Cout*kh*kw, B*H*W]
-                else:
-                    g_cols = _patch_matrix(g.permute(1, 0, 2, 3), kh, kw, kh - 1 - ph, kw - 1 - pw)
                 w_t = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * kh * kw)
-                d_x = _mm(w_t, g_cols).view(cin, b, h, w)
+                if ctx.implicit and hip_learner.conv3_supported(g, w_t):
+                    d_x = hip_learner.conv3_mm(w_t, g).view(cin, b, h, w)
+                else:
+                    if g.is_cuda:
+                        g_cols = hip_learner.patch_matrix_cm(g, kh, kw, kh - 1 - ph, kw - 1 - pw)  # [Cout*kh*kw, B*H*W]
+                    else:
+                        g_cols = _patch_matrix(g.permute(1, 0, 2, 3), kh, kw, kh - 1 - ph, kw - 1 - pw)
+                    d_x = _mm(w_t, g_cols).view(cin, b, h, w)
         return d_x, d_w, None, None
 
 

@@ -253,6 +253,43 @@ def mm3(a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None) -> t
     return out
 
 
+def conv3_supported(x: torch.Tensor, a: torch.Tensor) -> bool:
+    """True when the 3x3 / padding-1 products of ``a [M, K]`` with the patch matrix of channel-major ``x [Cin, B, H, W]`` can
+    run without materialising the patch matrix (:func:`conv3_mm`, :func:`conv3_wgrad`)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and a.dtype == torch.float32 and x.dim() == 4 and a.dim() == 2 and available()):
+        return False
+    cin, nb, h, w = (int(v) for v in x.shape)
+    pos = nb * h * w
+    return bool(x.is_contiguous() and cin % 4 == 0 and pos % 4 == 0 and pos < 2**24 and a.stride(1) == 1 and a.stride(0) % 4 == 0
+                and x.data_ptr() % 16 == 0 and a.data_ptr() % 16 == 0)
+
+
+def conv3_mm(a: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """``a [M, Cin * 9] @ patches(x)`` -> ``[M, B * H * W]`` for a 3x3, padding-1 convolution over channel-major ``x [Cin, B, H, W]``;
+    the patch matrix is generated inside the GEMM's operand loader (``gemm3_kernel`` B_MODE 2)."""
+    cin, nb, h, w = (int(v) for v in x.shape)
+    m = int(a.shape[0])
+    if a.shape[1] != cin * 9:
+        raise ValueError("conv3_mm: a must be [M, Cin * 9]")
+    out = torch.empty(m, nb * h * w, dtype=torch.float32, device=x.device)
+    hb.call("atri_conv3_gemm", hb.ptr(a), hb.ptr(x), hb.ptr(out), hb.i32(m), hb.i32(cin), hb.i32(nb), hb.i32(h), hb.i32(w),
+            hb.i64(a.stride(0)), hb.i32(0), hb.i32(0))
+    return out
+
+
+def conv3_wgrad(g2: torch.Tensor, x: torch.Tensor, chunk: int) -> torch.Tensor:
+    """Split-K weight-gradient partials ``[positions / chunk, M, Cin * 9]`` of a 3x3, padding-1 convolution: slice ``z`` is
+    ``g2[:, z*chunk:(z+1)*chunk] @ patches(x)[:, same]^T`` (``gemm3_kernel`` B_MODE 3); the caller adds the slices."""
+    cin, nb, h, w = (int(v) for v in x.shape)
+    m, pos = int(g2.shape[0]), nb * h * w
+    if g2.shape[1] != pos or pos % chunk or chunk % 4:
+        raise ValueError("conv3_wgrad: g2 must be [M, B * H * W] and chunk a multiple of 4 that divides the positions")
+    out = torch.empty(pos // chunk, m, cin * 9, dtype=torch.float32, device=x.device)
+    hb.call("atri_conv3_gemm", hb.ptr(g2), hb.ptr(x), hb.ptr(out), hb.i32(m), hb.i32(cin), hb.i32(nb), hb.i32(h), hb.i32(w),
+            hb.i64(g2.stride(0)), hb.i32(1), hb.i32(chunk))
+    return out
+
+
 # ---------------------------------------------------------------- fused multi-head self-attention (32-wide heads)
 def attention_supported(qkv: torch.Tensor, heads: int) -> bool:
     """True when :func:`attention_forward` handles packed ``qkv [L, B, 3 * 32 * heads]`` (bf16 or f32, up to 256 tokens)."""

@@ -362,8 +362,8 @@ def test_fused_batchnorm_act_kernels_match_torch(dtype, act, with_residual):
     assert int(bn.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("preset", ["default", "cnn"])
-def test_fp32_learner_fast_path_matches_stock_modules(preset):
+@pytest.mark.parametrize("preset,patch_free", [("default", False), ("cnn", False), ("default", True)])
+def test_fp32_learner_fast_path_matches_stock_modules(preset, patch_free):
     """fp32 (no autocast): channel-major body + fused BatchNorm / attention kernels + bf16-matrix-core GEMMs against the plain
     NCHW module path on the library's fp32 GEMMs - same outputs, gradients and running statistics to fp32 rounding, both
     measured against an fp64 run of the same step."""
@@ -398,12 +398,14 @@ def test_fp32_learner_fast_path_matches_stock_modules(preset):
     for net, dt, fast_gemm, low in ((net_a, torch.float32, True, False), (net_b, torch.float32, False, False),
                                     (net_c, torch.float64, False, False), (net_d, torch.float32, True, True)):
         model_mod.FP32_GEMM_ON_BF16_CORES = fast_gemm  # the comparison side runs on the library's fp32 GEMMs
+        model_mod.PATCH_FREE_CONV = patch_free and net is net_a  # LEARNER_PATCH_FREE_CONV: no patch matrices in memory
         try:
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=low):
                 pl, vl = net(grid.to(dt), other.to(dt))
             (pl.float().square().mean() + vl.float().square().mean()).backward() if low else (pl.square().mean() + vl.square().mean()).backward()
         finally:
             model_mod.FP32_GEMM_ON_BF16_CORES = True
+            model_mod.PATCH_FREE_CONV = False
         res.append((pl.detach().double(), vl.detach().double(), {n: p.grad.double() for n, p in net.named_parameters()}))
     torch.cuda.synchronize()
     assert (res[0][0] - res[2][0]).abs().max().item() < 2e-4 and (res[0][1] - res[2][1]).abs().max().item() < 2e-4
@@ -631,3 +633,42 @@ def test_fp32_training_trajectory_is_the_same_on_both_gemm_paths():
     # two fp32 runs that differ in rounding drift apart step by step (the gradients of the first layers amplify forward
     # rounding about a thousandfold, see the fast-path test above); the three-pass path has to stay well inside 1 %
     assert rel.max() < 1e-2
+
+
+@pytest.mark.parametrize("cin,cout,batch,h,w", [(128, 128, 256, 8, 15), (32, 64, 64, 8, 15), (64, 128, 8, 12, 21), (4, 32, 4, 5, 6), (128, 100, 16, 8, 15)])
+def test_patch_free_conv_gemms_match_torch_convolution(cin, cout, batch, h, w):
+    """3x3 / padding-1 convolution forward, data gradient and split-K weight gradient through gemm3_kernel's on-the-fly
+    patch loaders (no patch matrix in memory) against an fp64 convolution."""
+    from alphatriangle_amd.models.model import _split_count
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(53)
+    dev = torch.device("cuda")
+    x = torch.randn(cin, batch, h, w, device=dev)
+    wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.1
+    g = torch.randn(cout, batch, h, w, device=dev)
+    w2 = wt.reshape(cout, -1)
+    assert hip_learner.conv3_supported(x, w2)
+    out = hip_learner.conv3_mm(w2, x).view(cout, batch, h, w)
+    n = batch * h * w
+    s = _split_count(n)
+    d_w = hip_learner.conv3_wgrad(g.view(cout, n), x, n // s).sum(0).view(cout, cin, 3, 3)
+    d_x = None
+    w_t = wt.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * 9)
+    if hip_learner.conv3_supported(g, w_t):
+        d_x = hip_learner.conv3_mm(w_t, g).view(cin, batch, h, w)
+    torch.cuda.synchronize()
+
+    xr = x.double().permute(1, 0, 2, 3).requires_grad_(True)
+    wr = wt.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wr, padding=1)
+    ref.backward(g.double().permute(1, 0, 2, 3))
+
+    def rel(a, b):
+        return (a.double() - b).abs().max().item() / b.abs().max().item()
+
+    e_f, e_w = rel(out, ref.detach().permute(1, 0, 2, 3)), rel(d_w, wr.grad)
+    e_x = rel(d_x, xr.grad.permute(1, 0, 2, 3)) if d_x is not None else 0.0
+    print(f"[{cin}->{cout}, {batch} x {h}x{w}] forward {e_f:.2e}, weight gradient {e_w:.2e}, data gradient {e_x:.2e}")
+    assert e_f < 2e-5 and e_w < 2e-5 and e_x < 2e-5
+    assert d_x is not None or cout % 4 != 0
