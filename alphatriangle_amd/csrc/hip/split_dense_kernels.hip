@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256, 2) void fc_rows_split_kernel(const float* __re
                                                               const unsigned short* __restrict__ Wp, long long lo_off,
                                                               float* __restrict__ slabs, int B, int HW, int other_pad, int N,
                                                               int steps_per_split, const int* __restrict__ live) {
-  __shared__ __attribute__((aligned(16))) unsigned char xs[2][MT * 16 * kPitch];
+  __shared__ __attribute__((aligned(16))) unsigned char xs[2][2][MT * 16 * kPitch];  // [buffer][plane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b0 = blockIdx.x * (MT * 16);
@@ -67,21 +67,16 @@ __global__ __launch_bounds__(256, 2) void fc_rows_split_kernel(const float* __re
       }
     }
   };
-  float4 v[MT][2];
-  load_rows(s_begin, v);
-  for (int s0 = s_begin; s0 < s_end; s0 += 4) {
-    short8 wh[4][2], wl[4][2];
-    if (wave_active) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int step = min(s0 + ks, s_end - 1);  // steps beyond the split are loaded but not multiplied
-        wh[ks][0] = wph[(size_t)step * 512];
-        wh[ks][1] = wph[(size_t)step * 512 + 64];
-        wl[ks][0] = wpl[(size_t)step * 512];
-        wl[ks][1] = wpl[(size_t)step * 512 + 64];
-      }
-    }
-    __syncthreads();  // the previous iteration's MFMAs are done reading the tile
+  // Sum over the 16 lanes that share (lane >> 4): quad permutes, half-row mirror, row mirror - all DPP, no LDS round trip.
+  auto sum16 = [](float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+    return x;
+  };
+  // registers -> (LayerNorm) -> the two bf16 planes of tile buffer `buf`
+  auto stage = [&](const float4 (&v)[MT][2], int s0, int buf) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int c = tid + i * 256, r = c >> 4, cc = c & 15;
@@ -90,39 +85,63 @@ __global__ __launch_bounds__(256, 2) void fc_rows_split_kernel(const float* __re
         float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += f[j];
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-        const float mean = s * (1.0f / 128.0f);
+        const float mean = sum16(s) * (1.0f / 128.0f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           f[j] -= mean;
           ss += f[j] * f[j];
         }
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
-        const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
+        const float rstd = rsqrtf(sum16(ss) * (1.0f / 128.0f) + eps);
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = f[j] * rstd * gg[j] + bb[j];
       }
       short8 xh, xl;
       split_bf16x8(f, xh, xl);
-      *reinterpret_cast<short8*>(xs[0] + r * kPitch + cc * 16) = xh;
-      *reinterpret_cast<short8*>(xs[1] + r * kPitch + cc * 16) = xl;
+      *reinterpret_cast<short8*>(xs[buf][0] + r * kPitch + cc * 16) = xh;
+      *reinterpret_cast<short8*>(xs[buf][1] + r * kPitch + cc * 16) = xl;
     }
-    __syncthreads();
-    load_rows(s0 + 4, v);  // next pixel row: in flight during the MFMAs below
-    if (!wave_active) continue;
+  };
+  short8 wh[4][2], wl[4][2];
+  auto load_weights = [&](int s0) {
+    if (!wave_active) return;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (s0 + ks >= s_end) break;
+      const int step = min(s0 + ks, s_end - 1);  // steps beyond the split are loaded but not multiplied
+      wh[ks][0] = wph[(size_t)step * 512];
+      wh[ks][1] = wph[(size_t)step * 512 + 64];
+      wl[ks][0] = wpl[(size_t)step * 512];
+      wl[ks][1] = wpl[(size_t)step * 512 + 64];
+    }
+  };
+  // Two tile buffers: while a wave multiplies pixel row s0 out of one, the next row (already in flight from memory) is
+  // normalised, split and stored into the other; one barrier per row.  The weights of the next row are requested as soon
+  // as this row's MFMAs are issued.
+  float4 v[MT][2];
+  load_weights(s_begin);
+  load_rows(s_begin, v);
+  stage(v, s_begin, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int s0 = s_begin; s0 < s_end; s0 += 4, buf ^= 1) {
+    load_rows(s0 + 4, v);  // next pixel row: in flight during the MFMAs below
+    if (wave_active) {
 #pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const short8 xh = *reinterpret_cast<const short8*>(xs[0] + (t * 16 + l15) * kPitch + ks * 64 + q4 * 16);
-        const short8 xl = *reinterpret_cast<const short8*>(xs[1] + (t * 16 + l15) * kPitch + ks * 64 + q4 * 16);
-        acc[t][0] = mfma_split(wh[ks][0], wl[ks][0], xh, xl, acc[t][0]);
-        acc[t][1] = mfma_split(wh[ks][1], wl[ks][1], xh, xl, acc[t][1]);
+      for (int ks = 0; ks < 4; ++ks) {
+        if (s0 + ks >= s_end) break;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const short8 xh = *reinterpret_cast<const short8*>(xs[buf][0] + (t * 16 + l15) * kPitch + ks * 64 + q4 * 16);
+          const short8 xl = *reinterpret_cast<const short8*>(xs[buf][1] + (t * 16 + l15) * kPitch + ks * 64 + q4 * 16);
+          acc[t][0] = mfma_split(wh[ks][0], wl[ks][0], xh, xl, acc[t][0]);
+          acc[t][1] = mfma_split(wh[ks][1], wl[ks][1], xh, xl, acc[t][1]);
+        }
       }
     }
+    if (s0 + 4 < s_end) {
+      load_weights(s0 + 4);
+      stage(v, s0 + 4, buf ^ 1);  // the other buffer: its readers finished before the previous barrier
+    }
+    __syncthreads();
   }
   if (!wave_active) return;
   float* slab = slabs + (size_t)blockIdx.y * B * 128;
