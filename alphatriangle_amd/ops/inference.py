@@ -559,12 +559,10 @@ class InferenceEngine:
         synchronisation (the count is read on the device, also when the launches are replayed from a HIP graph).
         Kernels of the less common paths that do not read the count simply evaluate all rows.
         """
-        if live is None:
-            return self._forward_all(grid, other)
-        if live.dtype != torch.int32 or live.numel() != 1 or not live.is_cuda:
+        if live is not None and (live.dtype != torch.int32 or live.numel() != 1 or not live.is_cuda):
             raise ValueError("live must be one int32 on the engine's device")
         set_live = getattr(hb.lib(), "atri_set_live_count")
-        with _LIVE_LOCK:
+        with _LIVE_LOCK:  # also without a count: another thread's count must not leak into these launches
             set_live(hb.ptr(live))
             try:
                 return self._forward_all(grid, other)

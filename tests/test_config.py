@@ -89,3 +89,20 @@ def test_print_config_and_system(capsys):
     assert APP_NAME == "AlphaTriangle"
     with pytest.raises(ValidationError):
         SystemConfig(REPLAY_HBM_BUDGET_GB=400)
+
+
+def test_learner_gemm_mode_is_applied_to_the_model_module():
+    import alphatriangle_amd.models.model as model_mod
+
+    try:
+        SystemConfig(LEARNER_FP32_GEMM="library", LEARNER_PATCH_FREE_CONV=True).apply_learner_gemm_mode()
+        assert model_mod.FP32_GEMM_ON_BF16_CORES is False and model_mod.PATCH_FREE_CONV is True
+        SystemConfig().apply_learner_gemm_mode()
+        assert model_mod.FP32_GEMM_ON_BF16_CORES is True and model_mod.PATCH_FREE_CONV is False
+        with pytest.raises(ValidationError):
+            SystemConfig(LEARNER_FP32_GEMM="fp16")
+    finally:
+        model_mod.FP32_GEMM_ON_BF16_CORES, model_mod.PATCH_FREE_CONV = True, False
+    sc = SystemConfig()
+    assert sc.COMPACT_LEAF_BATCH is True and sc.INFERENCE_DTYPE == "fp32" and sc.learner_autocast() is False
+    assert SystemConfig(INFERENCE_DTYPE="bf16").learner_autocast() is True
