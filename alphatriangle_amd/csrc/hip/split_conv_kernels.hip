@@ -64,8 +64,9 @@ __device__ __forceinline__ float4v act4s(float4v v, int act) {
   return act == kActNone ? v : act4_slow(v, act);
 }
 
-// One 3x3 convolution of this wave's 32 output channels over the (hi, lo) halo tiles behind base_hi / base_lo.
-template <int CIN>
+// One 3x3 convolution of this wave's 32 output channels over the (hi, lo) halo tiles behind base_hi / base_lo, output
+// image rows T0 .. T0 + NT - 1 (the image rows one above and one below that range are read as well).
+template <int CIN, int T0 = 0, int NT = 8>
 __device__ __forceinline__ void split_mainloop(float4v (&acc)[8][2], const unsigned short* __restrict__ wsrc, long long lo_off,
                                                const unsigned char* base_hi, const unsigned char* base_lo, int wave, int lane) {
   constexpr int stride = CIN * 2 + 32;
@@ -73,6 +74,7 @@ __device__ __forceinline__ void split_mainloop(float4v (&acc)[8][2], const unsig
   const short8* wph = reinterpret_cast<const short8*>(wsrc) + (size_t)wave * 128 + lane;
   const short8* wpl = reinterpret_cast<const short8*>(wsrc + lo_off) + (size_t)wave * 128 + lane;
   (void)STEPS;
+  constexpr int R0 = T0 > 0 ? T0 - 1 : 0, R1 = T0 + NT < 8 ? T0 + NT : 7, NR = R1 - R0 + 1;  // image rows read
 #define SPLIT_WSTEP(g, dyi) ((((dyi) * 3 + (g) % 3) * KC) + (g) / 3)
   // tile row of image row r at horizontal tap dxi: (r * 16 + l15 + 1) + (dxi - 1); l15 is in the lane base
 #define SPLIT_ROW(g, r) (((r) * 16 + ((g) % 3)) * stride + ((g) / 3) * 64)
@@ -86,14 +88,14 @@ __device__ __forceinline__ void split_mainloop(float4v (&acc)[8][2], const unsig
   }
 #pragma unroll
   for (int i = 0; i < kAheadS; ++i) {
-    xh[i] = *reinterpret_cast<const short8*>(base_hi + SPLIT_ROW(i >> 3, i & 7));
-    xl[i] = *reinterpret_cast<const short8*>(base_lo + SPLIT_ROW(i >> 3, i & 7));
+    xh[i] = *reinterpret_cast<const short8*>(base_hi + SPLIT_ROW(i / NR, R0 + i % NR));
+    xl[i] = *reinterpret_cast<const short8*>(base_lo + SPLIT_ROW(i / NR, R0 + i % NR));
   }
 #pragma unroll
-  for (int i = 0; i < GROUPS * 8; ++i) {
-    const int g = i >> 3, r = i & 7, wc = g & 1, wn = wc ^ 1;
+  for (int i = 0; i < GROUPS * NR; ++i) {
+    const int g = i / NR, r = R0 + i % NR, wc = g & 1, wn = wc ^ 1;
     __builtin_amdgcn_sched_barrier(0);
-    if (r == 0 && g + 1 < GROUPS) {
+    if (r == R0 && g + 1 < GROUPS) {
 #pragma unroll
       for (int dyi = 0; dyi < 3; ++dyi) {
         wh[wn][dyi][0] = wph[(size_t)SPLIT_WSTEP(g + 1, dyi) * 512];
@@ -102,9 +104,9 @@ __device__ __forceinline__ void split_mainloop(float4v (&acc)[8][2], const unsig
         wl[wn][dyi][1] = wpl[(size_t)SPLIT_WSTEP(g + 1, dyi) * 512 + 64];
       }
     }
-    if (i + kAheadS < GROUPS * 8) {
-      xh[(i + kAheadS) % (kAheadS + 1)] = *reinterpret_cast<const short8*>(base_hi + SPLIT_ROW((i + kAheadS) >> 3, (i + kAheadS) & 7));
-      xl[(i + kAheadS) % (kAheadS + 1)] = *reinterpret_cast<const short8*>(base_lo + SPLIT_ROW((i + kAheadS) >> 3, (i + kAheadS) & 7));
+    if (i + kAheadS < GROUPS * NR) {
+      xh[(i + kAheadS) % (kAheadS + 1)] = *reinterpret_cast<const short8*>(base_hi + SPLIT_ROW((i + kAheadS) / NR, R0 + (i + kAheadS) % NR));
+      xl[(i + kAheadS) % (kAheadS + 1)] = *reinterpret_cast<const short8*>(base_lo + SPLIT_ROW((i + kAheadS) / NR, R0 + (i + kAheadS) % NR));
     }
     __builtin_amdgcn_sched_barrier(0);
     const short8 ah = xh[i % (kAheadS + 1)], al = xl[i % (kAheadS + 1)];
@@ -112,7 +114,7 @@ __device__ __forceinline__ void split_mainloop(float4v (&acc)[8][2], const unsig
 #pragma unroll
     for (int dyi = 0; dyi < 3; ++dyi) {
       const int t = r + 1 - dyi;
-      if (t < 0 || t > 7) continue;
+      if (t < T0 || t >= T0 + NT) continue;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[wc][dyi][n], ah, acc[t][n], 0, 0, 0);
@@ -230,13 +232,16 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
   float* otile = reinterpret_cast<float*>(smem);
 
   const int ch_wave = wave * 32;
+  // A 64-channel first convolution of a pair (the conv stem's middle layer) would occupy two of the four waves: it is
+  // split by image rows as well, wave -> (channel block wave & 1, rows 4 (wave >> 1) .. + 3).
+  constexpr bool kRowSplit = PAIR && CIN2 != CIN && CIN2 == 64;
   float4v acc[8][2];
 #pragma unroll(CIN2 != CIN ? 2 : 1)
   for (int stage = 0; stage < (PAIR ? 2 : 1); ++stage) {
     const unsigned short* wsrc = (PAIR && stage == 1) ? a.w2 : a.w;
     const long long lo_off = (PAIR && stage == 1) ? a.lo_off2 : a.lo_off;
     const float* bsrc = (PAIR && stage == 1) ? a.bias2 : a.bias;
-    const bool active = (PAIR && stage == 0) ? (ch_wave < CIN2) : (ch_wave < a.Cout);  // wave-uniform
+    const bool active = (PAIR && stage == 0) ? (kRowSplit || ch_wave < CIN2) : (ch_wave < a.Cout);  // wave-uniform
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
@@ -245,21 +250,26 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
     if (active) {
       if (PAIR && stage == 1 && CIN2 != CIN)
         split_mainloop<CIN2>(acc, wsrc, lo_off, b2h, b2l, wave, lane);
+      else if (kRowSplit && stage == 0 && wave < 2)
+        split_mainloop<CIN, 0, 4>(acc, wsrc, lo_off, b1h, b1l, wave & 1, lane);
+      else if (kRowSplit && stage == 0)
+        split_mainloop<CIN, 4, 4>(acc, wsrc, lo_off, b1h, b1l, wave & 1, lane);
       else
         split_mainloop<CIN>(acc, wsrc, lo_off, b1h, b1l, wave, lane);
     }
     __syncthreads();  // every wave is done reading the input tile (the next writes alias it)
+    const int cw = (kRowSplit && stage == 0) ? (wave & 1) : wave;  // channel block of this wave in this stage
     float bias[8];
     if (active) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bias[i] = bsrc[ch_wave + q4 * 8 + i];
+      for (int i = 0; i < 8; ++i) bias[i] = bsrc[cw * 32 + q4 * 8 + i];
     }
     if (PAIR && stage == 0) {
       // first convolution: bias + activation in fp32, split, back into the halo tile as the second one's input
       if (active && l15 < W) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          if (t >= H) continue;
+          if (t >= H || (kRowSplit && (t >> 2) != (wave >> 1))) continue;
           float4v lo = acc[t][0], hi = acc[t][1];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
           const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           short8 oh, ol;
           split_bf16x8(f, oh, ol);
-          const int off = (t * 16 + l15 + 1) * stride2 + wave * 64 + q4 * 16;
+          const int off = (t * 16 + l15 + 1) * stride2 + cw * 64 + q4 * 16;
           *reinterpret_cast<short8*>(t2h + off) = oh;
           *reinterpret_cast<short8*>(t2l + off) = ol;
         }
