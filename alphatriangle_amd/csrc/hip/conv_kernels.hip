@@ -55,8 +55,9 @@ __device__ __noinline__ float4v act8_slow_rc(float4v v, int act) {
 
 namespace {
 // One 3x3 convolution of this wave's 32 output channels over the halo tile behind lane_base:
-// acc[t][n] += W x tile for the 8 image rows t.
-template <int CIN, int DBG>
+// acc[t][n] += W x tile for the output image rows t = T0 .. T0 + NT - 1 (the image rows one above and one below
+// that range are read as well).
+template <int CIN, int DBG, int T0 = 0, int NT = 8>
 __device__ __forceinline__ void rowconv_mainloop(float4v (&acc)[8][2], const unsigned short* __restrict__ wsrc, int nb,
                                                  const unsigned char* lane_base, int wave, int lane) {
   constexpr int stride = CIN * 2 + 32;
@@ -70,6 +71,7 @@ __device__ __forceinline__ void rowconv_mainloop(float4v (&acc)[8][2], const uns
   // compiler from sinking those loads down to their first use.
   const short8* wp = reinterpret_cast<const short8*>(wsrc) + ((size_t)nb * STEPS * 4 + wave) * 128 + lane;
   constexpr int GROUPS = 3 * KC;
+  constexpr int R0 = T0 > 0 ? T0 - 1 : 0, R1 = T0 + NT < 8 ? T0 + NT : 7, NR = R1 - R0 + 1;  // image rows read
   // group g -> kc = g / 3, dxi = g % 3; weight step of vertical tap dyi: (dyi * 3 + dxi) * KC + kc
 #define ROWCONV_WSTEP(g, dyi) ((((dyi) * 3 + (g) % 3) * KC) + (g) / 3)
   // LDS byte offset (relative to lane_base) of image row r at horizontal tap dxi of channel chunk kc
@@ -81,32 +83,34 @@ __device__ __forceinline__ void rowconv_mainloop(float4v (&acc)[8][2], const uns
     wg[0][dyi][1] = wp[(size_t)ROWCONV_WSTEP(0, dyi) * 512 + 64];
   }
 #pragma unroll
-  for (int i = 0; i < kAhead; ++i) av[i] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW(i >> 3, i & 7));
+  for (int i = 0; i < kAhead; ++i) av[i] = *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW(i / NR, R0 + i % NR));
 #pragma unroll
-  for (int i = 0; i < GROUPS * 8; ++i) {
-    const int g = i >> 3, r = i & 7, wc = g & 1, wn = wc ^ 1;
+  for (int i = 0; i < GROUPS * NR; ++i) {
+    const int g = i / NR, r = R0 + i % NR, wc = g & 1, wn = wc ^ 1;
     __builtin_amdgcn_sched_barrier(0);
-    if (r == 0 && g + 1 < GROUPS) {
+    if (r == R0 && g + 1 < GROUPS) {
 #pragma unroll
       for (int dyi = 0; dyi < 3; ++dyi) {
         wg[wn][dyi][0] = (DBG & 2) ? wg[wc][dyi][0] : wp[(size_t)ROWCONV_WSTEP(g + 1, dyi) * 512];
         wg[wn][dyi][1] = (DBG & 2) ? wg[wc][dyi][1] : wp[(size_t)ROWCONV_WSTEP(g + 1, dyi) * 512 + 64];
       }
     }
-    if (i + kAhead < GROUPS * 8)
+    if (i + kAhead < GROUPS * NR)
       av[(i + kAhead) % (kAhead + 1)] =
           (DBG & 1) ? av[i % (kAhead + 1)]
-                    : *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW((i + kAhead) >> 3, (i + kAhead) & 7));
+                    : *reinterpret_cast<const short8*>(lane_base + ROWCONV_ROW((i + kAhead) / NR, R0 + (i + kAhead) % NR));
     __builtin_amdgcn_sched_barrier(0);
     const short8 x = av[i % (kAhead + 1)];
     // image row r feeds output row r - 1 through the dy = +1 tap, row r through dy = 0, row r + 1 through dy = -1
-    if (r >= 1) {
+    if (r - 1 >= T0 && r - 1 < T0 + NT) {
       acc[r - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][2][0], x, acc[r - 1][0], 0, 0, 0);
       acc[r - 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][2][1], x, acc[r - 1][1], 0, 0, 0);
     }
-    acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][1][0], x, acc[r][0], 0, 0, 0);
-    acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][1][1], x, acc[r][1], 0, 0, 0);
-    if (r <= 6) {
+    if (r >= T0 && r < T0 + NT) {
+      acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][1][0], x, acc[r][0], 0, 0, 0);
+      acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][1][1], x, acc[r][1], 0, 0, 0);
+    }
+    if (r + 1 >= T0 && r + 1 < T0 + NT) {
       acc[r + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][0][0], x, acc[r + 1][0], 0, 0, 0);
       acc[r + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[wc][0][1], x, acc[r + 1][1], 0, 0, 0);
     }
@@ -220,6 +224,9 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
   const unsigned char* lane_base2 = tile2 + l15 * stride2 + q4 * 16;
   unsigned char* otile = smem + a.out_off;
 
+  // A 64-channel first convolution of a pair (the conv stem's middle layer) would occupy two of the four waves: it is
+  // split by image rows as well, wave -> (channel block wave & 1, rows 4 (wave >> 1) .. + 3).
+  constexpr bool kRowSplit = PAIR && CIN2 != CIN && CIN2 == 64;
   for (int nb = 0; nb < a.n_blocks; ++nb) {
     const int ch_wave = nb * 128 + wave * 32;
     float4v acc[8][2];
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
     const unsigned short* wsrc = (PAIR && stage == 1) ? a.w2 : a.w;
     const float* bsrc = (PAIR && stage == 1) ? a.bias2 : a.bias;
     // wave-uniform; the first convolution of a pair has CIN2 output channels
-    const bool active = (PAIR && stage == 0) ? (wave * 32 < CIN2) : (ch_wave < a.Cout);
+    const bool active = (PAIR && stage == 0) ? (kRowSplit || wave * 32 < CIN2) : (ch_wave < a.Cout);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
@@ -238,21 +245,26 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
     if (active && !(DBG & 4)) {
       if (PAIR && stage == 1 && CIN2 != CIN)
         rowconv_mainloop<CIN2, DBG>(acc, wsrc, nb, lane_base2, wave, lane);
+      else if (kRowSplit && stage == 0 && wave < 2)
+        rowconv_mainloop<CIN, DBG, 0, 4>(acc, wsrc, nb, lane_base, wave & 1, lane);
+      else if (kRowSplit && stage == 0)
+        rowconv_mainloop<CIN, DBG, 4, 4>(acc, wsrc, nb, lane_base, wave & 1, lane);
       else
         rowconv_mainloop<CIN, DBG>(acc, wsrc, nb, lane_base, wave, lane);
     }
     __syncthreads();  // every wave is done reading the input tile (the output tile may alias it)
+    const int cw = (kRowSplit && stage == 0) ? (wave & 1) : wave;  // channel block of this wave in this stage
     float bias[8];
     if (active) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bias[i] = bsrc[ch_wave + q4 * 8 + i];
+      for (int i = 0; i < 8; ++i) bias[i] = bsrc[nb * 128 + cw * 32 + q4 * 8 + i];
     }
     if (PAIR && stage == 0) {
       // first convolution of the block: bias + activation, back into the halo tile as the second one's input
       if (active && l15 < W) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          if (t >= H) continue;
+          if (t >= H || (kRowSplit && (t >> 2) != (wave >> 1))) continue;
           float4v lo = acc[t][0], hi = acc[t][1];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256, 3) void rowconv_kernel(RowConvArgs a) {
             lo = act8_slow_rc(lo, a.act);
             hi = act8_slow_rc(hi, a.act);
           }
-          *reinterpret_cast<short8*>(tile2 + (17 + t * 16 + l15) * stride2 + wave * 64 + q4 * 16) =
+          *reinterpret_cast<short8*>(tile2 + (17 + t * 16 + l15) * stride2 + cw * 64 + q4 * 16) =
               pack_bf16x8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
         }
       }
