@@ -166,18 +166,19 @@ __global__ void per_set_leaves_kernel(double* tree, long long P, const int* idx,
 }
 
 // Recompute the ancestors of the given leaves, level by level, inside ONE workgroup (the
-// barrier between levels makes every level-k sum visible before level k-1 reads it).
+// barrier between levels makes every level-k sum visible before level k-1 reads it; __syncthreads orders the
+// workgroup's global writes and reads).
 __global__ void per_update_paths_kernel(double* tree, long long P, int levels, const int* idx, const int* count_ptr,
                                         int count_max) {
   const int n = count_ptr ? min(*count_ptr, count_max) : count_max;
-  for (int base = 0; base < n; base += blockDim.x) {
-    const int i = base + threadIdx.x;
-    long long node = i < n ? P + idx[i] : 0;
-    for (int l = 0; l < levels; ++l) {
-      node >>= 1;
-      if (i < n) tree[node] = tree[2 * node] + tree[2 * node + 1];
-      __syncthreads();
+  // Level-major: one barrier per tree level however many leaves there are, and a thread's loads of one level are all
+  // in flight together.  Leaves that share an ancestor write the same sum to it.
+  for (int l = 1; l <= levels; ++l) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const long long node = (P + idx[i]) >> l;
+      tree[node] = tree[2 * node] + tree[2 * node + 1];
     }
+    __syncthreads();
   }
 }
 
