@@ -7,15 +7,26 @@
 using namespace atrihip;
 
 namespace {
-constexpr int kPitch = 272;  // bytes per 128-wide bf16 LDS row (256 + 16)
+constexpr int kPitch = 288;  // bytes per 128-wide bf16 LDS row (256 + 32): 16-byte fragment reads of 16 rows x 4 column groups hit distinct banks
 }
 
-// Shared FC fed directly by the body's [B][HW][128] fp32 rows.  The final LayerNorm - when there is one - is
-// applied in fp32 to each 128-wide pixel row while it is staged (16 lanes per row), the row is then split into
-// the two bf16 planes; the "other" features are read from the caller's f32 rows as the last K steps.
-// steps_per_split is a multiple of 4, so every staged chunk of 4 K-steps is exactly one pixel row.
-template <int MT>
-__global__ __launch_bounds__(256, 2) void fc_rows_split_kernel(const float* __restrict__ rows, const float* __restrict__ other,
+// Shared FC fed directly by the body's [B][HW][128] fp32 rows, 64 samples x one K split per workgroup.  The final
+// LayerNorm - when there is one - is applied in fp32 to each 128-wide pixel row while it is staged (16 lanes per row;
+// LN = 1: normalisation only, the affine part folded into the weights by the host; LN = 2: with the affine part),
+// the row is then split into the two bf16 planes; the "other" features are read from the caller's f32 rows as the last
+// K steps.  steps_per_split is a multiple of 4, so every staged chunk of 4 K-steps is exactly one pixel row.
+//
+// The workgroup is specialised: waves 4-7 are producers (global rows -> LayerNorm -> split -> LDS tile), waves 0-3 are
+// consumers (wave = 32 output channels; three MFMA passes per product out of the tile).  One pixel row is only 96
+// MFMAs per consumer wave - far less than a memory round trip - so the producers keep kFcDepth pixel rows in flight in
+// the registers the consumers spend on accumulators and weights; with one barrier per pixel row the consumers never
+// wait for memory, only for the producers' staging arithmetic, which runs on the vector pipe beside their MFMAs.
+// Both loops are straight-line code (addresses are clamped instead of predicated, rows past the live count compute
+// on a valid row and are never stored): only then does the compiler's wait-count bookkeeping leave the younger loads
+// in flight while it waits for the oldest.
+// kFcDepth: pixel rows requested ahead of the one being staged.
+template <int MT, int LN, int kFcDepth>
+__global__ __launch_bounds__(512, 1) void fc_rows_split_kernel(const float* __restrict__ rows, const float* __restrict__ other,
                                                               int other_dim, const float* __restrict__ g,
                                                               const float* __restrict__ bt, float eps,
                                                               const unsigned short* __restrict__ Wp, long long lo_off,
@@ -23,7 +34,6 @@ __global__ __launch_bounds__(256, 2) void fc_rows_split_kernel(const float* __re
                                                               int steps_per_split, const int* __restrict__ live) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[2][2][MT * 16 * kPitch];  // [buffer][plane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q4 = lane >> 4, l15 = lane & 15;
   const int b0 = blockIdx.x * (MT * 16);
   const int nB = live_rows(live, B);  // rows that hold leaves; B stays the slab pitch
   if (b0 >= nB) return;               // whole workgroup, before any barrier
@@ -31,117 +41,165 @@ __global__ __launch_bounds__(256, 2) void fc_rows_split_kernel(const float* __re
   const int total_steps = feat_steps + (other_pad >> 5);
   const int s_begin = blockIdx.y * steps_per_split;
   const int s_end = min(s_begin + steps_per_split, total_steps);
+  if (s_begin >= s_end) return;
+  const int n_rows = (s_end - s_begin + 3) >> 2;                                          // chunks of 4 K-steps in this split
+  const int n_feat = s_begin < feat_steps ? (min(s_end, feat_steps) - s_begin) >> 2 : 0;  // of which pixel rows of the body
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers
+    const int pt = tid - 256;  // chunk c = pt + i * 256 -> sample row c >> 4, 8-channel piece c & 15
+    float gg[8], bb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gg[j] = LN == 2 ? g[(pt & 15) * 8 + j] : 1.f;
+      bb[j] = LN == 2 ? bt[(pt & 15) * 8 + j] : 0.f;
+    }
+    // Sum over the 16 lanes that share (lane >> 4): quad permutes, half-row mirror, row mirror - all DPP, no LDS round trip.
+    auto sum16 = [](float x) {
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+      return x;
+    };
+    // this thread's four (sample, 8-channel piece) sources at pixel row 0; samples past the live count read the last one
+    const float* src[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int c = pt + i * 256, r = c >> 4, cc = c & 15;
+      src[i] = rows + (size_t)min(b0 + r, nB - 1) * HW * 128 + cc * 8;
+    }
+    const int p0 = s_begin >> 2, p_last = max(p0 + n_feat - 1, 0);
+    // body pixel row f of this split into registers; rows past the split's last one re-read it (loaded, never staged)
+    auto issue = [&](int f, float4 (&v)[MT][2]) {
+      const size_t off = (size_t)min(p0 + f, p_last) * 128;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float4* p = reinterpret_cast<const float4*>(src[i] + off);
+        v[i][0] = p[0];
+        v[i][1] = p[1];
+      }
+    };
+    auto put = [&](const float (&f)[8], int i, int buf) {
+      const int c = pt + i * 256, r = c >> 4, cc = c & 15;
+      short8 xh, xl;
+      split_bf16x8(f, xh, xl);
+      *reinterpret_cast<short8*>(xs[buf][0] + r * kPitch + cc * 16) = xh;
+      *reinterpret_cast<short8*>(xs[buf][1] + r * kPitch + cc * 16) = xl;
+    };
+    // registers -> (LayerNorm) -> the two bf16 planes of tile buffer `buf`
+    auto stage = [&](const float4 (&v)[MT][2], int buf) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float f[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
+        if (LN != 0) {
+          float s = 0.f, ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s += f[j];
+          const float mean = sum16(s) * (1.0f / 128.0f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            f[j] -= mean;
+            ss += f[j] * f[j];
+          }
+          const float rstd = __builtin_amdgcn_rsqf(sum16(ss) * (1.0f / 128.0f) + eps);  // the argument is >= eps: no denormal case
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = LN == 2 ? f[j] * rstd * gg[j] + bb[j] : f[j] * rstd;
+        }
+        put(f, i, buf);
+      }
+    };
+    // chunk k of the "other" features (zero padded to other_pad; steps past the split's end become zero columns)
+    auto stage_other = [&](int k, int buf) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int c = pt + i * 256, r = c >> 4, cc = c & 15;
+        const int d0 = k * 128 + cc * 8;
+        const float* orow = other + (size_t)min(b0 + r, nB - 1) * other_dim;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = d0 + j < other_dim ? orow[d0 + j] : 0.f;
+        put(f, i, buf);
+      }
+    };
+    float4 v[kFcDepth][MT][2];
+#pragma unroll
+    for (int d = 0; d < kFcDepth; ++d) issue(d, v[d]);
+    // chunk i is staged during iteration i - 1 (chunk 0 before the loop); a body row's register slot is then refilled
+    // with the row kFcDepth further on
+    if (n_feat > 0) {
+      stage(v[0], 0);
+      issue(kFcDepth, v[0]);
+    } else {
+      stage_other(0, 0);
+    }
+    __syncthreads();
+    int i = 0;  // the chunk the consumers multiply now
+    for (; i + kFcDepth < n_feat; i += kFcDepth) {  // kFcDepth iterations with static register slots, no branches inside
+#pragma unroll
+      for (int d = 0; d < kFcDepth; ++d) {
+        constexpr int kD = kFcDepth;
+        stage(v[(d + 1) % kD], (i + d + 1) & 1);
+        issue(i + d + 1 + kD, v[(d + 1) % kD]);
+        __syncthreads();
+      }
+    }
+    // remaining iterations: fewer than kFcDepth body rows, then the chunks of "other" features
+#pragma unroll
+    for (int d = 0; d < kFcDepth; ++d) {
+      if (i + d + 1 < n_feat) {
+        stage(v[(d + 1) % kFcDepth], (i + d + 1) & 1);
+        __syncthreads();
+      }
+    }
+    i = max(n_feat - 1, 0);
+    for (; i < n_rows; ++i) {
+      if (i + 1 < n_rows) stage_other(i + 1 - n_feat, (i + 1) & 1);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const bool wave_active = wave * 32 < N;
   float4v acc[MT][2];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
     acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
   }
-  const bool wave_active = wave * 32 < N;
-  const short8* wph = reinterpret_cast<const short8*>(Wp) + (size_t)wave * 128 + lane;
-  const short8* wpl = reinterpret_cast<const short8*>(Wp + lo_off) + (size_t)wave * 128 + lane;
-  float gg[8], bb[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    gg[j] = g != nullptr ? g[(tid & 15) * 8 + j] : 1.f;
-    bb[j] = g != nullptr ? bt[(tid & 15) * 8 + j] : 0.f;
-  }
-  auto load_rows = [&](int s0, float4 (&v)[MT][2]) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int c = tid + i * 256, r = c >> 4, cc = c & 15;
-      v[i][0] = v[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (s0 < s_end && b0 + r < nB) {
-        if (s0 < feat_steps) {
-          const float4* p = reinterpret_cast<const float4*>(rows + ((size_t)(b0 + r) * HW + (s0 >> 2)) * 128 + cc * 8);
-          v[i][0] = p[0];
-          v[i][1] = p[1];
-        } else {  // the "other" features (zero padded to other_pad)
-          const int d0 = (s0 - feat_steps) * 32 + cc * 8;
-          float f[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = d0 + j < other_dim ? other[(size_t)(b0 + r) * other_dim + d0 + j] : 0.f;
-          v[i][0] = make_float4(f[0], f[1], f[2], f[3]);
-          v[i][1] = make_float4(f[4], f[5], f[6], f[7]);
-        }
-      }
-    }
-  };
-  // Sum over the 16 lanes that share (lane >> 4): quad permutes, half-row mirror, row mirror - all DPP, no LDS round trip.
-  auto sum16 = [](float x) {
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
-    return x;
-  };
-  // registers -> (LayerNorm) -> the two bf16 planes of tile buffer `buf`
-  auto stage = [&](const float4 (&v)[MT][2], int s0, int buf) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int c = tid + i * 256, r = c >> 4, cc = c & 15;
-      float f[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
-      if (g != nullptr && s0 < feat_steps) {  // block-uniform branch: all 16 lanes of a row take it together
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += f[j];
-        const float mean = sum16(s) * (1.0f / 128.0f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          f[j] -= mean;
-          ss += f[j] * f[j];
-        }
-        const float rstd = rsqrtf(sum16(ss) * (1.0f / 128.0f) + eps);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = f[j] * rstd * gg[j] + bb[j];
-      }
-      short8 xh, xl;
-      split_bf16x8(f, xh, xl);
-      *reinterpret_cast<short8*>(xs[buf][0] + r * kPitch + cc * 16) = xh;
-      *reinterpret_cast<short8*>(xs[buf][1] + r * kPitch + cc * 16) = xl;
-    }
-  };
+  const int wv = wave_active ? wave : 0;  // idle waves read valid fragments and drop the result
+  const short8* wph = reinterpret_cast<const short8*>(Wp) + (size_t)wv * 128 + lane;
+  const short8* wpl = reinterpret_cast<const short8*>(Wp + lo_off) + (size_t)wv * 128 + lane;
   short8 wh[4][2], wl[4][2];
-  auto load_weights = [&](int s0) {
-    if (!wave_active) return;
+  // K-steps past the split's end are staged as zero columns; their weights are the last step's again (finite)
+  auto load_wslice = [&](int s0, int ks) {
+    const size_t step = (size_t)min(s0 + ks, s_end - 1) * 512;
+    wh[ks][0] = wph[step];
+    wh[ks][1] = wph[step + 64];
+    wl[ks][0] = wpl[step];
+    wl[ks][1] = wpl[step + 64];
+  };
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) load_wslice(s_begin, ks);
+  __syncthreads();  // chunk 0 is staged
+  for (int i = 0; i < n_rows; ++i) {
+    const int s0 = s_begin + 4 * i;
+    const unsigned char* xh_base = xs[i & 1][0] + l15 * kPitch + q4 * 16;
+    const unsigned char* xl_base = xs[i & 1][1] + l15 * kPitch + q4 * 16;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int step = min(s0 + ks, s_end - 1);  // steps beyond the split are loaded but not multiplied
-      wh[ks][0] = wph[(size_t)step * 512];
-      wh[ks][1] = wph[(size_t)step * 512 + 64];
-      wl[ks][0] = wpl[(size_t)step * 512];
-      wl[ks][1] = wpl[(size_t)step * 512 + 64];
-    }
-  };
-  // Two tile buffers: while a wave multiplies pixel row s0 out of one, the next row (already in flight from memory) is
-  // normalised, split and stored into the other; one barrier per row.  The weights of the next row are requested as soon
-  // as this row's MFMAs are issued.
-  float4 v[MT][2];
-  load_weights(s_begin);
-  load_rows(s_begin, v);
-  stage(v, s_begin, 0);
-  __syncthreads();
-  int buf = 0;
-  for (int s0 = s_begin; s0 < s_end; s0 += 4, buf ^= 1) {
-    load_rows(s0 + 4, v);  // next pixel row: in flight during the MFMAs below
-    if (wave_active) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (s0 + ks >= s_end) break;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const short8 xh = *reinterpret_cast<const short8*>(xs[buf][0] + (t * 16 + l15) * kPitch + ks * 64 + q4 * 16);
-          const short8 xl = *reinterpret_cast<const short8*>(xs[buf][1] + (t * 16 + l15) * kPitch + ks * 64 + q4 * 16);
-          acc[t][0] = mfma_split(wh[ks][0], wl[ks][0], xh, xl, acc[t][0]);
-          acc[t][1] = mfma_split(wh[ks][1], wl[ks][1], xh, xl, acc[t][1]);
-        }
+      for (int t = 0; t < MT; ++t) {
+        const short8 xh = *reinterpret_cast<const short8*>(xh_base + t * 16 * kPitch + ks * 64);
+        const short8 xl = *reinterpret_cast<const short8*>(xl_base + t * 16 * kPitch + ks * 64);
+        acc[t][0] = mfma_split(wh[ks][0], wl[ks][0], xh, xl, acc[t][0]);
+        acc[t][1] = mfma_split(wh[ks][1], wl[ks][1], xh, xl, acc[t][1]);
       }
+      load_wslice(s0 + 4, ks);  // the slice just used takes the next chunk's weights
     }
-    if (s0 + 4 < s_end) {
-      load_weights(s0 + 4);
-      stage(v, s0 + 4, buf ^ 1);  // the other buffer: its readers finished before the previous barrier
-    }
-    __syncthreads();
+    __syncthreads();  // chunk i + 1 is staged; every consumer is past its reads of this buffer
   }
   if (!wave_active) return;
   float* slab = slabs + (size_t)blockIdx.y * B * 128;
@@ -350,10 +408,20 @@ int atri_split_fc_rows(const float* rows, const float* other, int other_dim, con
   if (D != 128 || (other_pad & 31) != 0 || other_dim < 0 || other_dim > other_pad || N > 128 || (N & 31) != 0) return -10;
   if ((steps_per_split & 3) != 0 || steps_per_split <= 0) return -11;
   if ((long long)SK * steps_per_split < (long long)HW * 4 + (other_pad >> 5)) return -12;
-  // 64 samples per workgroup: with three MFMA passes per product the loop is matrix-core bound, and the 128-sample
-  // variant of the bf16 kernel (half the weight reads from L2) does not fit the register file next to the lo fragments
-  hipLaunchKernelGGL(fc_rows_split_kernel<4>, dim3((B + 63) / 64, SK), dim3(256), 0, stream, rows, other, other_dim, g, bt, eps,
-                       (const unsigned short*)Wp, lo_off, slabs, B, HW, other_pad, N, steps_per_split, live_count_ptr());
+  // 64 samples x one K split per 8-wave workgroup (one per CU).  g == nullptr with eps > 0: LayerNorm without an affine part
+  // (the host folded it into Wp and the bias); eps == 0: no LayerNorm.
+  const dim3 grid((B + 63) / 64, SK);
+#define ATRI_FC_LAUNCH(LN)                                                                                                \
+  hipLaunchKernelGGL((fc_rows_split_kernel<4, LN, 4>), grid, dim3(512), 0, stream, rows, other, other_dim, g, bt, eps,    \
+                     (const unsigned short*)Wp, lo_off, slabs, B, HW, other_pad, N, steps_per_split, live_count_ptr())
+  if (g != nullptr) {
+    ATRI_FC_LAUNCH(2);
+  } else if (eps > 0.f) {
+    ATRI_FC_LAUNCH(1);
+  } else {
+    ATRI_FC_LAUNCH(0);
+  }
+#undef ATRI_FC_LAUNCH
   return hip_err(hipGetLastError());
 }
 

@@ -348,7 +348,7 @@ class InferenceEngine:
         # ---- transformer
         self.tf_layers: list[dict[str, Any]] = []
         self.proj: _GemmLayer | None = None
-        self.final_ln: tuple[torch.Tensor, torch.Tensor, float] | None = None
+        self.final_ln: tuple[torch.Tensor | None, torch.Tensor | None, float] | None = None
         if self.uses_tf:
             pe = model.pos_encoder.pe[: self.HW, 0, :].detach().float().contiguous().to(dev)
             if isinstance(model.input_proj, nn.Conv2d):
@@ -402,6 +402,13 @@ class InferenceEngine:
         w, b = _fold_bn(lin0.weight, lin0.bias, bnf)  # [N, feat + other]
         feat = self.HW * self.feat_c
         wf = w[:, :feat]
+        if self.split and self.uses_tf:
+            # fp32 engine: the final LayerNorm's affine part goes into the FC (the kernel only normalises the rows)
+            fn = model.transformer_body.norm
+            gf, bf = fn.weight.detach().float().to(w.device), fn.bias.detach().float().to(w.device)
+            b = b + wf @ bf.repeat(self.HW)
+            wf = wf * gf.repeat(self.HW)[None, :]
+            self.final_ln = (None, None, float(fn.eps))
         if not self.uses_tf:  # PyTorch flattens NCHW (c*HW + p); activations here are NHWC (p*C + c)
             wf = wf.reshape(-1, self.feat_c, self.HW).permute(0, 2, 1).reshape(-1, feat)
         wo = torch.zeros(w.shape[0], self.other_pad, device=w.device)
@@ -420,7 +427,9 @@ class InferenceEngine:
         self.policy_layers = [self._linear_layer(l, bn, self.act if a else 0) for l, bn, a in _split_seq(model.policy_head)]
         self.value_layers = [self._linear_layer(l, bn, self.act if a else 0) for l, bn, a in _split_seq(model.value_head)]
         total_steps = self.fc_kp // 32
-        self.fc_sk = max(1, min(16, total_steps // 16))
+        # K splits of the shared FC.  The fp32 kernel runs one 8-wave workgroup per CU on 64 samples x one split:
+        # 4 splits of a 4096-leaf wave are one workgroup per CU of a 256-CU device.
+        self.fc_sk = max(1, min(4 if self.split else 16, total_steps // 16))
         # 128-channel bodies feed the FC straight from their NHWC rows (flatten + final LayerNorm fused into its staging)
         self.fc_fused = self.feat_c == 128 and self.fc_n <= 128
         if self.fc_fused:

@@ -197,3 +197,51 @@ def test_search_picks_the_same_moves_under_bf16_fp32_engine_and_fp32_module():
     print(f"bf16 engine vs fp32 module: same move {s16:.4f}, mean KL {kl16:.3e}, max KL {klmax16:.3e}")
     assert s32 >= 0.99 and kl32 < 1e-3
     assert s16 >= 0.95 and kl16 < 0.05
+
+
+@pytest.mark.parametrize("ln_mode", ["affine", "plain", "none"])
+@pytest.mark.parametrize("batch,live", [(70, None), (200, 131)])
+def test_fp32_shared_fc_kernel_matches_fp64(ln_mode, batch, live):
+    """The split-K shared-FC kernel on its own: body rows (+ LayerNorm in its three forms) and the "other" features
+    against an fp64 evaluation, with K splits that end inside the body rows and inside the "other" chunk, sample counts
+    that are no multiple of the tile, and a device-side live count."""
+    from alphatriangle_amd.ops import hipbind as hb
+    from alphatriangle_amd.ops.inference import pack_gemm_weights_split
+
+    dev = torch.device("cuda")
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    HW, other_dim, other_pad, N = 6, 30, 32, 128
+    rows = (torch.randn(batch, HW, 128, generator=gen) * 1.5 + 0.3).to(dev)
+    other = torch.rand(batch, other_dim, generator=gen).to(dev)
+    kp = HW * 128 + other_pad
+    w = torch.zeros(kp, N)
+    w[: HW * 128 + other_dim] = torch.randn(HW * 128 + other_dim, N, generator=gen) * 0.05
+    g = (torch.rand(128, generator=gen) + 0.5).to(dev)
+    bt = (torch.randn(128, generator=gen) * 0.1).to(dev)
+    eps = 1e-5
+    packed, _, lo = pack_gemm_weights_split(w.unsqueeze(0), dev)
+    sk, steps_per_split = 2, 16  # 25 K-steps: split 0 = four pixel rows, split 1 = two pixel rows + the "other" chunk
+    slabs = torch.full((sk, batch, 128), float("nan"), device=dev)
+    live_t = None if live is None else torch.tensor([live], dtype=torch.int32, device=dev)
+    set_live = getattr(hb.lib(), "atri_set_live_count")
+    set_live(hb.ptr(live_t))
+    try:
+        hb.call("atri_split_fc_rows", hb.ptr(rows), hb.ptr(other), hb.i32(other_dim), hb.ptr(g if ln_mode == "affine" else None),
+                hb.ptr(bt if ln_mode == "affine" else None), hb.f32(0.0 if ln_mode == "none" else eps), hb.ptr(packed), hb.i64(lo),
+                hb.ptr(slabs), hb.i32(batch), hb.i32(HW), hb.i32(128), hb.i32(other_pad), hb.i32(N), hb.i32(sk), hb.i32(steps_per_split))
+    finally:
+        set_live(hb.VP(0))
+    torch.cuda.synchronize()
+    x = rows.double()
+    if ln_mode != "none":
+        x = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + eps)
+        if ln_mode == "affine":
+            x = x * g.double() + bt.double()
+    feats = torch.cat([x.reshape(batch, -1), other.double(), torch.zeros(batch, other_pad - other_dim, dtype=torch.float64, device=dev)], dim=1)
+    ref = feats @ w.double().to(dev)
+    n = batch if live is None else live
+    out = slabs[:, :n].double().sum(0)
+    scale = float(ref[:n].abs().max())
+    assert float((out - ref[:n]).abs().max()) < 2e-5 * scale
+    if live is not None:  # rows past the live count are not written
+        assert torch.isnan(slabs[:, n:]).all()
