@@ -498,20 +498,28 @@ __global__ __launch_bounds__(256, 2) void fc_splitk_kernel(const unsigned short*
 
 // Shared FC fed directly by the body's NHWC rows (128 channels per pixel): the flatten is free (a sample's
 // rows are contiguous), the final LayerNorm - when there is one - is applied to each 128-wide pixel row while
-// it is staged into LDS (16 lanes per row, statistics by xor-shuffles), and the "other" features are read from the
-// caller's f32 rows as the last K steps.  Replaces rows_to_fc + fc_splitk and their 2 x 126 MB round trip.
+// it is staged into LDS (16 lanes per row), and the "other" features are read from the caller's f32 rows as the last
+// K steps.  Replaces rows_to_fc + fc_splitk and their 2 x 126 MB round trip.
 // steps_per_split is a multiple of 4, so every staged chunk of 4 K-steps is exactly one pixel row.
-template <int MT>
-__global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned short* __restrict__ rows /*[B][HW][128]*/,
+//
+// MT * 16 samples x one K split per 8-wave workgroup, specialised: waves 4-7 are producers (global rows ->
+// LayerNorm -> LDS tile, DEPTH pixel rows in flight in registers), waves 0-3 are consumers (wave = 32 output
+// channels, MFMAs out of the tile, the weight slice just used refilled with the next pixel row's).  One barrier per
+// pixel row, two tile buffers.  Both loops are straight-line code - addresses are clamped instead of predicated,
+// samples past the live count compute on a valid row and are never stored - so that the compiler's wait counts leave
+// the younger loads in flight (with branches in the loop it drains them all at every join).
+template <int MT, bool LN, int DEPTH>
+__global__ __launch_bounds__(512, 1) void fc_rows_splitk_kernel(const unsigned short* __restrict__ rows /*[B][HW][128]*/,
                                                                 const float* __restrict__ other /*[B][other_dim] f32*/,
                                                                 int other_dim,
                                                                 const float* __restrict__ g, const float* __restrict__ bt,
                                                                 float eps, const unsigned short* __restrict__ Wp,
                                                                 float* __restrict__ slabs, int B, int HW, int other_pad,
                                                                 int N, int steps_per_split, const int* __restrict__ live) {
-  __shared__ __attribute__((aligned(16))) unsigned char xs[MT * 16 * 272];
+  constexpr int kPitch = 288;  // bytes per tile row: 16-byte fragment reads of 16 rows x 4 column groups hit distinct banks
+  constexpr int CH = MT;       // 16-byte chunks per producer thread and pixel row
+  __shared__ __attribute__((aligned(16))) unsigned char xs[2][MT * 16 * kPitch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q4 = lane >> 4, l15 = lane & 15;
   const int b0 = blockIdx.x * (MT * 16);
   const int nB = live_rows(live, B);  // rows that hold leaves; B stays the slab pitch
   if (b0 >= nB) return;               // whole workgroup, before any barrier
@@ -519,94 +527,152 @@ __global__ __launch_bounds__(256, 2) void fc_rows_splitk_kernel(const unsigned s
   const int total_steps = feat_steps + (other_pad >> 5);
   const int s_begin = blockIdx.y * steps_per_split;
   const int s_end = min(s_begin + steps_per_split, total_steps);
+  if (s_begin >= s_end) return;
+  const int n_rows = (s_end - s_begin + 3) >> 2;                                          // chunks of 4 K-steps in this split
+  const int n_feat = s_begin < feat_steps ? (min(s_end, feat_steps) - s_begin) >> 2 : 0;  // of which pixel rows of the body
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers
+    const int pt = tid - 256;  // chunk c = pt + i * 256 -> sample row c >> 4, 8-channel piece c & 15
+    float gg[8], bb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gg[j] = LN ? g[(pt & 15) * 8 + j] : 1.f;
+      bb[j] = LN ? bt[(pt & 15) * 8 + j] : 0.f;
+    }
+    // Sum over the 16 lanes that share (lane >> 4): quad permutes, half-row mirror, row mirror - all DPP, no LDS round trip.
+    auto sum16 = [](float x) {
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+      return x;
+    };
+    const unsigned short* src[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = pt + i * 256, r = c >> 4, cc = c & 15;
+      src[i] = rows + (size_t)min(b0 + r, nB - 1) * HW * 128 + cc * 8;
+    }
+    const int p0 = s_begin >> 2, p_last = max(p0 + n_feat - 1, 0);
+    // body pixel row f of this split into registers; rows past the split's last one re-read it (loaded, never staged)
+    auto issue = [&](int f, uint4 (&v)[CH]) {
+      const size_t off = (size_t)min(p0 + f, p_last) * 128;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) v[i] = *reinterpret_cast<const uint4*>(src[i] + off);
+    };
+    auto put = [&](short8 x, int i, int buf) {
+      const int c = pt + i * 256, r = c >> 4, cc = c & 15;
+      *reinterpret_cast<short8*>(xs[buf] + r * kPitch + cc * 16) = x;
+    };
+    auto stage = [&](const uint4 (&v)[CH], int buf) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        short8 x = __builtin_bit_cast(short8, v[i]);
+        if (LN) {
+          float f[8], s = 0.f, ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            f[j] = bf16_to_float((unsigned short)x[j]);
+            s += f[j];
+            ss += f[j] * f[j];
+          }
+          s = sum16(s);
+          ss = sum16(ss);
+          const float mean = s * (1.0f / 128.0f);
+          const float rstd = rsqrtf(fmaxf(ss * (1.0f / 128.0f) - mean * mean, 0.f) + eps);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * rstd * gg[j] + bb[j];
+          x = pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+        }
+        put(x, i, buf);
+      }
+    };
+    // chunk k of the "other" features (zero padded to other_pad; steps past the split's end become zero columns)
+    auto stage_other = [&](int k, int buf) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = pt + i * 256, r = c >> 4, cc = c & 15;
+        const int d0 = k * 128 + cc * 8;
+        const float* orow = other + (size_t)min(b0 + r, nB - 1) * other_dim;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = d0 + j < other_dim ? orow[d0 + j] : 0.f;
+        put(pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]), i, buf);
+      }
+    };
+    uint4 v[DEPTH][CH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(d, v[d]);
+    // chunk i is staged during iteration i - 1 (chunk 0 before the loop); a body row's register slot is then refilled
+    // with the row DEPTH further on
+    if (n_feat > 0) {
+      stage(v[0], 0);
+      issue(DEPTH, v[0]);
+    } else {
+      stage_other(0, 0);
+    }
+    __syncthreads();
+    int i = 0;  // the chunk the consumers multiply now
+    for (; i + DEPTH < n_feat; i += DEPTH) {  // DEPTH iterations with static register slots, no branches inside
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        stage(v[(d + 1) % DEPTH], (i + d + 1) & 1);
+        issue(i + d + 1 + DEPTH, v[(d + 1) % DEPTH]);
+        __syncthreads();
+      }
+    }
+    // remaining iterations: fewer than DEPTH body rows, then the chunks of "other" features
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (i + d + 1 < n_feat) {
+        stage(v[(d + 1) % DEPTH], (i + d + 1) & 1);
+        __syncthreads();
+      }
+    }
+    i = max(n_feat - 1, 0);
+    for (; i < n_rows; ++i) {
+      if (i + 1 < n_rows) stage_other(i + 1 - n_feat, (i + 1) & 1);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const bool wave_active = wave * 32 < N;
   float4v acc[MT][2];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
     acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
   }
-  const bool wave_active = wave * 32 < N;
-  const short8* wp = reinterpret_cast<const short8*>(Wp) + (size_t)wave * 128 + lane;
-  // this thread's slice of gamma / beta (chunk cc = tid & 15 of the 128 channels)
-  float gg[8], bb[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    gg[j] = g != nullptr ? g[(tid & 15) * 8 + j] : 1.f;
-    bb[j] = g != nullptr ? bt[(tid & 15) * 8 + j] : 0.f;
-  }
-  // One pixel row (4 K-steps) of MT * 16 samples per iteration (128 samples per workgroup halve the weight reads
-  // from L2, which are twice the activation bytes at 64).  The rows of iteration i+1 and the weight fragments of
-  // iteration i are requested before the LayerNorm / MFMA work of iteration i, so neither HBM nor L2 latency is
-  // exposed once the loop is running.
-  auto load_rows = [&](int s0, uint4 (&v)[MT]) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int c = tid + i * 256, r = c >> 4, cc = c & 15;
-      v[i] = make_uint4(0, 0, 0, 0);
-      if (s0 < s_end && b0 + r < nB) {
-        if (s0 < feat_steps) {
-          v[i] = *reinterpret_cast<const uint4*>(rows + ((size_t)(b0 + r) * HW + (s0 >> 2)) * 128 + cc * 8);
-        } else {  // the "other" features: converted from the caller's f32 rows on the fly (zero padded to other_pad)
-          const int d0 = (s0 - feat_steps) * 32 + cc * 8;
-          float f[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = d0 + j < other_dim ? other[(size_t)(b0 + r) * other_dim + d0 + j] : 0.f;
-          v[i] = __builtin_bit_cast(uint4, pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]));
-        }
-      }
-    }
+  const int wv = wave_active ? wave : 0;  // idle waves read valid fragments and drop the result
+  const short8* wp = reinterpret_cast<const short8*>(Wp) + (size_t)wv * 128 + lane;
+  short8 wf[4][2];
+  // K-steps past the split's end are staged as zero columns; their weights are the last step's again (finite)
+  auto load_wslice = [&](int s0, int ks) {
+    const size_t step = (size_t)min(s0 + ks, s_end - 1) * 512;
+    wf[ks][0] = wp[step];
+    wf[ks][1] = wp[step + 64];
   };
-  uint4 v[MT];
-  load_rows(s_begin, v);
-  for (int s0 = s_begin; s0 < s_end; s0 += 4) {
-    short8 wf[4][2];
-    if (wave_active) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int step = min(s0 + ks, s_end - 1);  // steps beyond the split are loaded but not multiplied
-        wf[ks][0] = wp[(size_t)step * 512];
-        wf[ks][1] = wp[(size_t)step * 512 + 64];
-      }
-    }
-    __syncthreads();  // the previous iteration's MFMAs are done reading the tile
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int c = tid + i * 256, r = c >> 4, cc = c & 15;
-      short8 x = __builtin_bit_cast(short8, v[i]);
-      if (g != nullptr && s0 < feat_steps) {  // block-uniform branch: all 16 lanes of a row take it together
-        float f[8], s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          f[j] = bf16_to_float((unsigned short)x[j]);
-          s += f[j];
-          ss += f[j] * f[j];
-        }
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) {
-          s += __shfl_xor(s, off, 64);
-          ss += __shfl_xor(ss, off, 64);
-        }
-        const float mean = s * (1.0f / 128.0f);
-        const float rstd = rsqrtf(fmaxf(ss * (1.0f / 128.0f) - mean * mean, 0.f) + eps);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * rstd * gg[j] + bb[j];
-        x = pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
-      }
-      *reinterpret_cast<short8*>(xs + r * 272 + cc * 16) = x;
-    }
-    __syncthreads();
-    load_rows(s0 + 4, v);  // next pixel row: in flight during the MFMAs below
-    if (!wave_active) continue;
+  for (int ks = 0; ks < 4; ++ks) load_wslice(s_begin, ks);
+  __syncthreads();  // chunk 0 is staged
+  for (int i = 0; i < n_rows; ++i) {
+    const int s0 = s_begin + 4 * i;
+    const unsigned char* x_base = xs[i & 1] + l15 * kPitch + q4 * 16;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (s0 + ks >= s_end) break;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const short8 xv = *reinterpret_cast<const short8*>(xs + (t * 16 + l15) * 272 + ks * 64 + q4 * 16);
+        const short8 xv = *reinterpret_cast<const short8*>(x_base + t * 16 * kPitch + ks * 64);
         acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][0], xv, acc[t][0], 0, 0, 0);
         acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][1], xv, acc[t][1], 0, 0, 0);
       }
+      load_wslice(s0 + 4, ks);  // the slice just used takes the next chunk's weights
     }
+    __syncthreads();  // chunk i + 1 is staged; every consumer is past its reads of this buffer
   }
   if (!wave_active) return;
   float* slab = slabs + (size_t)blockIdx.y * B * 128;
@@ -849,14 +915,16 @@ int atri_fc_rows_splitk(const void* rows, const float* other, int other_dim, con
   if (D != 128 || (other_pad & 31) != 0 || other_dim < 0 || other_dim > other_pad || N > 128 || (N & 31) != 0) return -10;
   if ((steps_per_split & 3) != 0 || steps_per_split <= 0) return -11;
   if ((long long)SK * steps_per_split < (long long)HW * 4 + (other_pad >> 5)) return -12;
-  if (B >= 2048)  // enough samples to fill the chip with 128-sample workgroups
-    hipLaunchKernelGGL(fc_rows_splitk_kernel<8>, dim3((B + 127) / 128, SK), dim3(256), 0, stream, (const unsigned short*)rows,
-                       other, other_dim, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
-                       steps_per_split, live_count_ptr());
-  else
-    hipLaunchKernelGGL(fc_rows_splitk_kernel<4>, dim3((B + 63) / 64, SK), dim3(256), 0, stream, (const unsigned short*)rows,
-                       other, other_dim, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, other_pad, N,
-                       steps_per_split, live_count_ptr());
+#define ATRI_FC_LAUNCH(MT, LN)                                                                                      \
+  hipLaunchKernelGGL((fc_rows_splitk_kernel<MT, LN, 4>), dim3((B + MT * 16 - 1) / (MT * 16), SK), dim3(512), 0, stream, \
+                     (const unsigned short*)rows, other, other_dim, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, \
+                     other_pad, N, steps_per_split, live_count_ptr())
+  if (B >= 2048) {  // enough samples to fill the chip with 128-sample workgroups (half the weight reads of 64-sample ones)
+    if (g != nullptr) ATRI_FC_LAUNCH(8, true); else ATRI_FC_LAUNCH(8, false);
+  } else {
+    if (g != nullptr) ATRI_FC_LAUNCH(4, true); else ATRI_FC_LAUNCH(4, false);
+  }
+#undef ATRI_FC_LAUNCH
   return hip_err(hipGetLastError());
 }
 

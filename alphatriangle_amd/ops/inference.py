@@ -427,9 +427,9 @@ class InferenceEngine:
         self.policy_layers = [self._linear_layer(l, bn, self.act if a else 0) for l, bn, a in _split_seq(model.policy_head)]
         self.value_layers = [self._linear_layer(l, bn, self.act if a else 0) for l, bn, a in _split_seq(model.value_head)]
         total_steps = self.fc_kp // 32
-        # K splits of the shared FC.  The fp32 kernel runs one 8-wave workgroup per CU on 64 samples x one split:
-        # 4 splits of a 4096-leaf wave are one workgroup per CU of a 256-CU device.
-        self.fc_sk = max(1, min(4 if self.split else 16, total_steps // 16))
+        # K splits of the shared FC.  The FC kernels run one 8-wave workgroup per CU on 64 (fp32) or 128 (bf16) samples
+        # x one split: 4 / 8 splits of a 4096-leaf wave are one workgroup per CU of a 256-CU device.
+        self.fc_sk = max(1, min(4 if self.split else 8, total_steps // 16))
         # 128-channel bodies feed the FC straight from their NHWC rows (flatten + final LayerNorm fused into its staging)
         self.fc_fused = self.feat_c == 128 and self.fc_n <= 128
         if self.fc_fused:
