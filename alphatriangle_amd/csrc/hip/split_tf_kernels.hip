@@ -59,6 +59,11 @@ constexpr int kDs = 128;
 constexpr int kStrideS = 288;                  // bytes per token row of a bf16 plane
 constexpr int kPlane = 128 * kStrideS;         // 36,864
 constexpr int kRegion = 2 * kPlane;            // 73,728
+// Biases of the layer live in LDS behind the two regions (floats): [bqkv 384][bo 128][b2 128][b1 up to 512].  A bias
+// read from global memory right before its GEMM would be the youngest outstanding load, and waiting for it drains
+// every older one - the weight slices and residual rows that are meant to stay in flight.
+constexpr int kBiasQkv = 0, kBiasO = 384, kBias2 = 512, kBias1 = 640, kBiasFloats = 640 + 512;
+constexpr int kEncLds = 2 * kRegion + kBiasFloats * 4;  // 152,064
 
 typedef __attribute__((ext_vector_type(4))) short short4v;
 
@@ -263,11 +268,12 @@ __device__ __forceinline__ bool attention_tiles(const short8 (&qh)[4], const sho
 }
 }  // namespace
 
-template <int HALVES, bool PROBE>
+template <int HALVES, bool PROBE, int ACT>
 __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* A = smem;
   unsigned char* Bq = smem + kRegion;
+  float* sb = reinterpret_cast<float*>(smem + 2 * kRegion);
   const int HW = a.HW;
   const int nB = live_rows(a.live, a.B);
   if ((int)blockIdx.x >= nB) return;  // whole workgroup, before any barrier
@@ -279,6 +285,12 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   WSplit w;
   {
     const int tid = threadIdx.x;
+    if (tid < 384) sb[kBiasQkv + tid] = a.bqkv[tid];
+    if (tid < 128) {
+      sb[kBiasO + tid] = a.bo[tid];
+      sb[kBias2 + tid] = a.b2[tid];
+    }
+    if (tid < HALVES * 128) sb[kBias1 + tid] = a.b1[tid];  // visible after the first barrier of the sample loop
     load_wsplit(w, wref(a.wqkv, a.lo_qkv, (size_t)((tid >> 6) & 3) * 128 + (tid & 63) + (size_t)4 * 512));  // K weights fly during LayerNorm1
     LnRows first;
     ln_load(first, a.x + (size_t)blockIdx.x * HW * kDs, HW, tid);
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   {
     float bias[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[kDs + ch0 + i];
+    for (int i = 0; i < 8; ++i) bias[i] = sb[kBiasQkv + kDs + ch0 + i];
     float4v acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   short8 vth[4][2], vtl[4][2];
   {
     const int chp = (l15 >> 2) * 8 + (l15 & 3);
-    const float bv0 = a.bqkv[2 * kDs + cb * 32 + chp], bv1 = a.bqkv[2 * kDs + cb * 32 + chp + 4];
+    const float bv0 = sb[kBiasQkv + 2 * kDs + cb * 32 + chp], bv1 = sb[kBiasQkv + 2 * kDs + cb * 32 + chp + 4];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       float4v acc[4][2];
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   {
     float bias[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[ch0 + i];
+    for (int i = 0; i < 8; ++i) bias[i] = sb[kBiasQkv + ch0 + i];
     float4v acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -368,8 +380,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   }
   // One dword of every 128-byte line of this sample's input rows: the output projection adds them as the residual, and
   // by then they may have left L2 (the other workgroups of the XCD stream their own rows and outputs through it).
-  float touch = 0.f;
-  if (tid * 32 < HW * kDs) touch = xg[tid * 32];
+  const float touch = xg[min(tid * 32, HW * kDs - 1)];
   ATRI_PHASE(4);
   __syncthreads();  // K image complete; every wave is past its reads of LayerNorm1(x): region A takes the attention output
   ATRI_PHASE(5);
@@ -397,20 +408,19 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
     float4 res[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int r = (tile0 + t) * 16 + l15;
-      res[t][0] = res[t][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < HW) {
-        const float4* p = reinterpret_cast<const float4*>(xg + (size_t)r * kDs + ch0);
-        res[t][0] = p[0];
-        res[t][1] = p[1];
-      }
+      // unpredicated (padding rows read the last real row; their sums are never stored): no branch between these loads
+      // and the GEMM, so the compiler lets them fly through it
+      const int r = min((tile0 + t) * 16 + l15, HW - 1);
+      const float4* p = reinterpret_cast<const float4*>(xg + (size_t)r * kDs + ch0);
+      res[t][0] = p[0];
+      res[t][1] = p[1];
     }
-    if (__float_as_uint(touch) == 0x7FC5A5A5u) __builtin_amdgcn_s_sleep(1);  // keeps the touch alive; never true for real data
+    asm volatile("" ::"v"(touch));  // keeps the touch load alive
     if constexpr (PROBE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ATRI_PHASE(17);
     float bias[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = a.bo[ch0 + i];
+    for (int i = 0; i < 8; ++i) bias[i] = sb[kBiasO + ch0 + i];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       y[t][0] = (float4v){bias[0], bias[1], bias[2], bias[3]};
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   {
     float b2v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) b2v[i] = a.b2[ch0 + i];
+    for (int i = 0; i < 8; ++i) b2v[i] = sb[kBias2 + ch0 + i];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
     {
       float bias[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bias[i] = a.b1[h * 128 + ch0 + i];
+      for (int i = 0; i < 8; ++i) bias[i] = sb[kBias1 + h * 128 + ch0 + i];
       float4v acc[4][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float4v lo = acc[t][0], hi = acc[t][1];
-        if (a.act == kActReLU) {
+        if (ACT == kActReLU) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             lo[j] = fmaxf(lo[j], 0.f);
@@ -540,14 +550,19 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
 }
 
 namespace {
-template <int HALVES>
-int launch_enc(const SplitEncArgs& a, hipStream_t stream) {
+template <int HALVES, bool PROBE, int ACT>
+int launch_enc_inst(const SplitEncArgs& a, int grid, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)encoder_layer_split_kernel<HALVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kRegion);
-    (void)hipFuncSetAttribute((const void*)encoder_layer_split_kernel<HALVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kRegion);
+    (void)hipFuncSetAttribute((const void*)encoder_layer_split_kernel<HALVES, PROBE, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, kEncLds);
     attr = true;
   }
+  hipLaunchKernelGGL((encoder_layer_split_kernel<HALVES, PROBE, ACT>), dim3(grid), dim3(512), kEncLds, stream, a);
+  return hip_err(hipGetLastError());
+}
+
+template <int HALVES>
+int launch_enc(const SplitEncArgs& a, hipStream_t stream) {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
@@ -555,11 +570,11 @@ int launch_enc(const SplitEncArgs& a, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -20;
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  if (a.phase_clock != nullptr)
-    hipLaunchKernelGGL((encoder_layer_split_kernel<HALVES, true>), dim3(a.B < cus ? a.B : cus), dim3(512), 2 * kRegion, stream, a);
-  else
-    hipLaunchKernelGGL((encoder_layer_split_kernel<HALVES, false>), dim3(a.B < cus ? a.B : cus), dim3(512), 2 * kRegion, stream, a);
-  return hip_err(hipGetLastError());
+  const int grid = a.B < cus ? a.B : cus;
+  const bool relu = a.act == kActReLU;
+  if (a.phase_clock != nullptr)  // diagnostics build of the kernel
+    return relu ? launch_enc_inst<HALVES, true, kActReLU>(a, grid, stream) : launch_enc_inst<HALVES, true, kActGELU>(a, grid, stream);
+  return relu ? launch_enc_inst<HALVES, false, kActReLU>(a, grid, stream) : launch_enc_inst<HALVES, false, kActGELU>(a, grid, stream);
 }
 }  // namespace
 
