@@ -214,12 +214,13 @@ __device__ __forceinline__ bool attention_tiles(const short8 (&qh)[4], const sho
                                                 const short8 (&vtl)[4][2], const short8* kimg, unsigned char* A, int HW, int tile0,
                                                 int cb, int q4, int l15, WSplit& w, const WRef& after) {
   bool suspect = false;
-  float4v st[2][8];
-  attn_scores<TAIL>(st[0], kimg, qh[0], ql[0], HW, q4);
+  // One score tile at a time: a second one in flight (scores of tile t + 1 under the softmax of tile t) costs 32
+  // registers that the kernel does not have - they came back as spills whose reloads drain the in-flight loads.  The
+  // phase is bound by the vector pipe over both waves of a SIMD, so the matrix work of one wave hides under the other's.
+  float4v s[8];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    float4v(&s)[8] = st[t & 1];
-    if (t < 3) attn_scores<TAIL>(st[(t + 1) & 1], kimg, qh[t + 1], ql[t + 1], HW, q4);
+    attn_scores<TAIL>(s, kimg, qh[t], ql[t], HW, q4);
     if (!SAFE && t == 3) {  // the weights of the GEMM after attention fly during the last tile (the ring is idle until then)
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) load_wslice(w, kc, after);
