@@ -134,13 +134,17 @@ __device__ __forceinline__ void split_mainloop(float4v (&acc)[8][2], const unsig
 // convolution's activated output is split and written straight back into the halo tile, the second one runs from
 // there and takes the skip connection from the block input in memory.  CIN2 != CIN: two consecutive stem layers; the
 // first one's output goes into a second halo tile of CIN2 channels.
-template <int CIN, bool FIRST, bool PAIR, int CIN2>
+// RELU: the activation is ReLU (the reference's default) - compiled in, so that the epilogues and the write-back have
+// no per-chunk branches on the activation code; other activations go through the run-time form.
+template <int CIN, bool FIRST, bool PAIR, int CIN2, bool RELU>
 __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x;
   if (b >= live_rows(a.live, a.B)) return;  // whole workgroup, before any barrier
+  const int act = RELU ? (int)kActReLU : a.act;
+  const int first_act = RELU ? (int)kActReLU : a.first_act;
   constexpr int stride = CIN * 2 + 32;
   constexpr int stride2 = CIN2 * 2 + 32;
   constexpr int plane = kTileRows * stride, plane2 = kTileRows * stride2;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
           v[4] += gv * w1.x; v[5] += gv * w1.y; v[6] += gv * w1.z; v[7] += gv * w1.w;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], a.first_act);
+        for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], first_act);
         split_bf16x8(v, oh, ol);
       }
       *reinterpret_cast<short8*>(t1h + r * stride + cc * 16) = oh;
@@ -276,8 +280,8 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
             lo[j] += bias[j];
             hi[j] += bias[4 + j];
           }
-          lo = act4s(lo, a.act);
-          hi = act4s(hi, a.act);
+          lo = act4s(lo, act);
+          hi = act4s(hi, act);
           const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           short8 oh, ol;
           split_bf16x8(f, oh, ol);
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
       if (a.residual != nullptr) {
         v[0] += rv[i].x; v[1] += rv[i].y; v[2] += rv[i].z; v[3] += rv[i].w;
       }
-      v = act4s(v, a.act);
+      v = act4s(v, act);
       if (a.post_add != nullptr) {
         const float4 pa = *reinterpret_cast<const float4*>(a.post_add + (size_t)p * a.Cout + cc * 4);
         v[0] += pa.x; v[1] += pa.y; v[2] += pa.z; v[3] += pa.w;
@@ -339,15 +343,20 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
 }
 
 namespace {
-template <int CIN, bool FIRST, bool PAIR, int CIN2>
-int launch_split(const SplitConvArgs& a, int lds, hipStream_t stream) {
+template <int CIN, bool FIRST, bool PAIR, int CIN2, bool RELU>
+int launch_split_inst(const SplitConvArgs& a, int lds, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)rowconv_split_kernel<CIN, FIRST, PAIR, CIN2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)rowconv_split_kernel<CIN, FIRST, PAIR, CIN2, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((rowconv_split_kernel<CIN, FIRST, PAIR, CIN2>), dim3(a.B), dim3(256), lds, stream, a);  // a.live set by the callers
+  hipLaunchKernelGGL((rowconv_split_kernel<CIN, FIRST, PAIR, CIN2, RELU>), dim3(a.B), dim3(256), lds, stream, a);  // a.live set by the callers
   return hip_err(hipGetLastError());
+}
+template <int CIN, bool FIRST, bool PAIR, int CIN2>
+int launch_split(const SplitConvArgs& a, int lds, hipStream_t stream) {
+  const bool relu = a.act == kActReLU && (!FIRST || a.first_act == kActReLU);
+  return relu ? launch_split_inst<CIN, FIRST, PAIR, CIN2, true>(a, lds, stream) : launch_split_inst<CIN, FIRST, PAIR, CIN2, false>(a, lds, stream);
 }
 
 int check_geometry(int H, int W, int HW) {
