@@ -251,6 +251,13 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
       acc[t][0] = (float4v){0.f, 0.f, 0.f, 0.f};
       acc[t][1] = (float4v){0.f, 0.f, 0.f, 0.f};
     }
+    // the bias is requested before the main loop: read after it, it would be a memory round trip in front of the epilogue
+    const int cw = (kRowSplit && stage == 0) ? (wave & 1) : wave;  // channel block of this wave in this stage
+    float bias[8];
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bias[i] = bsrc[cw * 32 + q4 * 8 + i];
+    }
     if (active) {
       if (PAIR && stage == 1 && CIN2 != CIN)
         split_mainloop<CIN2>(acc, wsrc, lo_off, b2h, b2l, wave, lane);
@@ -262,12 +269,6 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
         split_mainloop<CIN>(acc, wsrc, lo_off, b1h, b1l, wave, lane);
     }
     __syncthreads();  // every wave is done reading the input tile (the next writes alias it)
-    const int cw = (kRowSplit && stage == 0) ? (wave & 1) : wave;  // channel block of this wave in this stage
-    float bias[8];
-    if (active) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) bias[i] = bsrc[cw * 32 + q4 * 8 + i];
-    }
     if (PAIR && stage == 0) {
       // first convolution: bias + activation in fp32, split, back into the halo tile as the second one's input
       if (active && l15 < W) {
