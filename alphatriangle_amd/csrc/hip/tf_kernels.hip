@@ -30,6 +30,7 @@ constexpr int kStride = 288;     // LDS bytes per token row: 18 slots of 16 B (e
                                  // 16 lanes of a ds_read_b128 cycle on 16 different bank quads
 constexpr int kRows = 128;       // token rows per tile (8 M-tiles of 16)
 constexpr int kTileBytes = kRows * kStride;
+constexpr int kLayerBiasBytes = (640 + 512) * 4;  // encoder_layer_kernel keeps the layer's biases behind its two tiles
 
 __device__ __forceinline__ short8 pack8(const float4v& lo, const float4v& hi) {
   return pack_bf16x8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
@@ -130,9 +131,10 @@ __device__ __forceinline__ void load_residual(ResFragsT<MT>& rf, const unsigned 
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    const int r = t * 16 + l15;
-    rf.r[t] = (short8){0, 0, 0, 0, 0, 0, 0, 0};
-    if (r < HW) rf.r[t] = *reinterpret_cast<const short8*>(rowbase + (size_t)r * kD);
+    // unpredicated (rows past the end re-read the last one; callers never store them): with a branch per load the
+    // compiler waits for these loads at the next GEMM's first step instead of letting them fly through it
+    const int r = min(t * 16 + l15, HW - 1);
+    rf.r[t] = *reinterpret_cast<const short8*>(rowbase + (size_t)r * kD);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -254,9 +256,11 @@ __device__ __forceinline__ bool attn_tiles(const short8 (&Kf)[8], const short8 (
 // On return every wave is past its last read of the xn tile; the ao tile may still be read by other waves.
 // FULL8: the token count is known to lie in (112, 128], i.e. eight query tiles and only the last key tile partly
 // padded; the tile loop and the padding masks then carry no run-time branches.
+// bqkv / bo: the biases as the body reads them - the kernel arguments, or copies in LDS (encoder_layer_kernel: a bias read
+// from memory in front of its GEMM is a round trip that nothing hides).
 template <int DBG, bool FULL8 = false>
 __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char* xn, unsigned char* ao, int b,
-                                          float4v (&y)[8][2]) {
+                                          float4v (&y)[8][2], const float* bqkv, const float* bo) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int HW = a.HW;
@@ -276,7 +280,7 @@ __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char*
   {  // ---- K_w (bias preloaded into the accumulators: the MFMA adds it for free)
     float bias[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[kD + wave * 32 + q4 * 8 + i];
+    for (int i = 0; i < 8; ++i) bias[i] = bqkv[kD + wave * 32 + q4 * 8 + i];
     float4v acc[8][2];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -291,7 +295,7 @@ __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char*
   __builtin_amdgcn_sched_barrier(0);
   {  // ---- V_w with swapped operands: acc[t][n][j] = V[token t*16 + 4q4 + j][dim perm(l15, n)]
     const int chp = (l15 >> 2) * 8 + (l15 & 3);
-    const float bv0 = a.bqkv[2 * kD + wave * 32 + chp], bv1 = a.bqkv[2 * kD + wave * 32 + chp + 4];
+    const float bv0 = bqkv[2 * kD + wave * 32 + chp], bv1 = bqkv[2 * kD + wave * 32 + chp + 4];
     float4v acc[8][2];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -311,7 +315,7 @@ __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char*
   {  // ---- Q_w : lane ends with dims 8q4..8q4+7 of token (t*16 + l15)
     float bias[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = a.bqkv[wave * 32 + q4 * 8 + i];
+    for (int i = 0; i < 8; ++i) bias[i] = bqkv[wave * 32 + q4 * 8 + i];
     float4v acc[8][2];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -342,7 +346,7 @@ __device__ __forceinline__ void attn_body(const AttnBlockArgs& a, unsigned char*
   if (!(DBG & 8)) gemm_k128<false>(acc, wb, ao, l15, q4);
   float bias[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) bias[i] = a.bo[ch0 + i];
+  for (int i = 0; i < 8; ++i) bias[i] = bo[ch0 + i];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(AttnBlockArgs a) {
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x;
   float4v y[8][2];
-  attn_body<DBG, FULL8>(a, smem, smem + kTileBytes, b, y);
+  attn_body<DBG, FULL8>(a, smem, smem + kTileBytes, b, y, a.bqkv, a.bo);
   const int ch0 = wave * 32 + q4 * 8;
   unsigned short* og = a.out + (size_t)b * a.HW * kD;
 #pragma unroll
@@ -627,10 +631,19 @@ __global__ __launch_bounds__(256, 2) void encoder_layer_kernel(EncoderLayerArgs 
   if (b >= live_rows(e.attn.live, e.attn.B)) return;  // whole workgroup, before any barrier
   const int HW = e.attn.HW;
   const int ch0 = wave * 32 + q4 * 8;
+  // biases in LDS behind the two tiles: [bqkv 384][bo 128][b2 128][b1 HALVES * 128]; visible after attn_body's first barrier
+  float* sb = reinterpret_cast<float*>(smem + 2 * kTileBytes);
+  sb[tid] = e.attn.bqkv[tid];
+  if (tid < 128) {
+    sb[256 + tid] = e.attn.bqkv[256 + tid];
+    sb[384 + tid] = e.attn.bo[tid];
+    sb[512 + tid] = e.b2[tid];
+  }
+  for (int i = tid; i < HALVES * 128; i += 256) sb[640 + i] = e.b1[i];
   float4v acc_o[8][2];
-  attn_body<0, FULL8>(e.attn, xn, hh, b, acc_o);
+  attn_body<0, FULL8>(e.attn, xn, hh, b, acc_o, sb, sb + 384);
 
-  ffn_tail<HALVES>(acc_o, xn, hh, HW, e.w1, e.b1, e.w2, e.b2, e.ln2_g, e.ln2_b, e.ln2_eps, e.act,
+  ffn_tail<HALVES>(acc_o, xn, hh, HW, e.w1, sb + 640, e.w2, sb + 512, e.ln2_g, e.ln2_b, e.ln2_eps, e.act,
                    e.attn.out + (size_t)b * HW * kD);
 }
 
@@ -668,10 +681,10 @@ template <int HALVES, bool FULL8>
 int launch_layer_inst(const EncoderLayerArgs& e, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)encoder_layer_kernel<HALVES, FULL8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes);
+    (void)hipFuncSetAttribute((const void*)encoder_layer_kernel<HALVES, FULL8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileBytes + kLayerBiasBytes);
     attr = true;
   }
-  hipLaunchKernelGGL((encoder_layer_kernel<HALVES, FULL8>), dim3(e.attn.B), dim3(256), 2 * kTileBytes, stream, e);
+  hipLaunchKernelGGL((encoder_layer_kernel<HALVES, FULL8>), dim3(e.attn.B), dim3(256), 2 * kTileBytes + kLayerBiasBytes, stream, e);
   return (int)hipGetLastError();
 }
 template <int HALVES>
