@@ -313,13 +313,22 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
   const int chunks = a.HW << l2c;
   const size_t gbase = (size_t)b * a.HW * a.Cout;
   for (int c0 = tid; c0 < chunks; c0 += 256 * 8) {
-    float4 rv[8];
+    // skip-connection rows and positional-table values of all eight chunks are requested before the first is used: a
+    // table value read inside the chunk loop would wait for the previous chunk's store as well (one counter for both)
+    float4 rv[8], pv[8];
     if (a.residual != nullptr) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = c0 + i * 256;
         rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < chunks) rv[i] = *reinterpret_cast<const float4*>(a.residual + gbase + (size_t)(c >> l2c) * a.Cout + (c & (cpp - 1)) * 4);
+      }
+    }
+    if (a.post_add != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = min(c0 + i * 256, chunks - 1);
+        pv[i] = *reinterpret_cast<const float4*>(a.post_add + (size_t)(c >> l2c) * a.Cout + (c & (cpp - 1)) * 4);
       }
     }
 #pragma unroll
@@ -335,8 +344,7 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
       }
       v = act4s(v, act);
       if (a.post_add != nullptr) {
-        const float4 pa = *reinterpret_cast<const float4*>(a.post_add + (size_t)p * a.Cout + cc * 4);
-        v[0] += pa.x; v[1] += pa.y; v[2] += pa.z; v[3] += pa.w;
+        v[0] += pv[i].x; v[1] += pv[i].y; v[2] += pv[i].z; v[3] += pv[i].w;
       }
       *reinterpret_cast<float4*>(a.out + gbase + (size_t)p * a.Cout + cc * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
