@@ -214,11 +214,17 @@ class NeuralNetwork:
 
     def set_weights(self, weights: dict[str, torch.Tensor]) -> None:
         try:
+            # checked before anything is copied: load_state_dict copies the tensors that fit before it reports the others
+            own = self._orig_model.state_dict()
+            bad = [k for k in own if k not in weights or tuple(weights[k].shape) != tuple(own[k].shape)]
+            bad += [k for k in weights if k not in own]
+            if bad:
+                raise ValueError(f"{len(bad)} parameter(s) differ in name or shape from this model, e.g. {bad[0]}")
             self._orig_model.load_state_dict({k: v.to(self.device) for k, v in weights.items()})
             self.model.eval()
             self.sync_inference_weights()
         except Exception as exc:
-            logger.error("Error setting weights on NN instance: %s", exc, exc_info=True)
+            logger.error("Error setting weights on NN instance: %s", exc)
             raise
 
     def sync_inference_weights(self) -> None:

@@ -28,10 +28,21 @@ def _load_and_apply_initial_state(components: TrainingComponents) -> TrainingLoo
     else:
         loop = TrainingLoop(components)
     ckpt = loaded.checkpoint_data
+    buf = loaded.buffer_data
+    if ckpt is not None and ckpt.model_state_dict:
+        # Auto-resume picks the latest run under the data root; when that run used another model or board configuration
+        # its weights do not fit.  That is a fresh start (weights, optimizer, counters and replay), not a failed run.
+        try:
+            components.nn.set_weights(ckpt.model_state_dict)
+        except Exception as exc:
+            logger.warning(
+                "Checkpoint of run %s (step %d) does not fit this model configuration (%s): starting fresh.",
+                ckpt.run_name, ckpt.global_step, str(exc).splitlines()[0],
+            )
+            ckpt = None
+            buf = None
     if ckpt is not None:
         logger.info("Applying loaded checkpoint data (Run: %s, Step: %d)", ckpt.run_name, ckpt.global_step)
-        if ckpt.model_state_dict:
-            components.nn.set_weights(ckpt.model_state_dict)
         if ckpt.optimizer_state_dict:
             try:
                 if components.trainer is not None:
@@ -45,7 +56,6 @@ def _load_and_apply_initial_state(components: TrainingComponents) -> TrainingLoo
     else:
         logger.info("No checkpoint data loaded. Starting fresh.")
         loop.set_initial_state(0, 0, 0)
-    buf = loaded.buffer_data
     if buf is not None and buf.buffer_list:
         logger.info("Rebuilding replay buffer from %d saved experiences (priorities restart at max).", len(buf.buffer_list))
         components.buffer.load_list(buf.buffer_list)

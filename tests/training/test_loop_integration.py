@@ -209,3 +209,24 @@ def test_end_to_end_cpu_training_with_resume(tmp_path):
                         env_config_override=env, system_config_override=system) == 0
     ck2 = Serializer().load_checkpoint(tmp_path / "E2E" / "runs" / "b" / "checkpoints" / "latest.pkl")
     assert ck2.global_step == 45 and ck2.episodes_played >= ck.episodes_played
+
+
+def test_resume_with_another_architecture_starts_fresh(tmp_path):
+    """Auto-resume finds the latest run under the data root; when that run's weights do not fit the configured
+    model the new run starts from scratch instead of failing (and copies nothing from the old weights)."""
+    env, model, mcts, train, system = build_preset("tiny")
+    train = train.model_copy(update={"MAX_TRAINING_STEPS": 10, "CHECKPOINT_SAVE_FREQ_STEPS": 10, "LR_SCHEDULER_T_MAX": 10, "PER_BETA_ANNEAL_STEPS": 10})
+    t1 = TrieyeConfig(app_name="E2E", run_name="a")
+    t1.persistence.ROOT_DATA_DIR = str(tmp_path)
+    assert run_training("WARNING", train, t1, profile=False, model_config_override=model, mcts_config_override=mcts,
+                        env_config_override=env, system_config_override=system) == 0
+    wider = model.model_copy(update={"FC_DIMS_SHARED": [model.FC_DIMS_SHARED[0] * 2]})
+    t2 = TrieyeConfig(app_name="E2E", run_name="b")
+    t2.persistence.ROOT_DATA_DIR = str(tmp_path)
+    shorter = train.model_copy(update={"MAX_TRAINING_STEPS": 6, "CHECKPOINT_SAVE_FREQ_STEPS": 6, "LR_SCHEDULER_T_MAX": 6, "PER_BETA_ANNEAL_STEPS": 6})
+    assert run_training("WARNING", shorter, t2, profile=False, model_config_override=wider, mcts_config_override=mcts,
+                        env_config_override=env, system_config_override=system) == 0
+    ck = Serializer().load_checkpoint(tmp_path / "E2E" / "runs" / "b" / "checkpoints" / "latest.pkl")
+    assert ck.global_step == 6  # counted from zero: a run resumed at run a's step 10 would have ended there
+    first = next(iter(ck.model_state_dict))
+    assert ck.model_state_dict["shared_fc.0.weight"].shape[0] == wider.FC_DIMS_SHARED[0], first
