@@ -284,3 +284,137 @@ int atri_bn_cm_bwd(const void* x, const void* r, const void* dy, int is_bf16, co
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Dropout fused with its neighbours in the encoder layer (alphatriangle/nn/model.py:189-196, the stock
+// nn.TransformerEncoderLayer): "stream + dropout(branch)" and "dropout(activation(hidden))", forward and backward.
+// The keep mask is a hash of (seed, element index), recomputed by the backward kernel: no mask tensor, no generator
+// state, and a captured learner step draws a new seed tensor on every replay.  Elements in eights (n % 8 == 0).
+namespace {
+__device__ __forceinline__ unsigned drop_hash32(unsigned idx, unsigned s0, unsigned s1) {
+  unsigned x = idx * 0x9E3779B1u + s0;
+  x ^= x >> 16; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x *= 0xC2B2AE35u;
+  x ^= x >> 16; x += s1;
+  x ^= x >> 15; x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  return x;
+}
+struct DropSeed {
+  unsigned s0, s1;
+};
+__device__ __forceinline__ DropSeed drop_seed(const long long* seed) {
+  const unsigned long long s = (unsigned long long)*seed;
+  return {(unsigned)s, (unsigned)(s >> 32)};
+}
+}  // namespace
+
+// out = a + dropout(b)  (dtype of a)
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void add_dropout_fwd_kernel(const TA* __restrict__ a, const TB* __restrict__ b, TA* __restrict__ out,
+                                                              const long long* __restrict__ seed, long long n, unsigned thresh, float scale) {
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i0 >= n) return;
+  const DropSeed s = drop_seed(seed);
+  float va[8], vb[8];
+  load8<TA>(a + i0, va);
+  load8<TB>(b + i0, vb);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) va[j] += drop_hash32((unsigned)(i0 + j), s.s0, s.s1) >= thresh ? vb[j] * scale : 0.f;
+  store8<TA>(out + i0, va);
+}
+
+// db = dropout'(g) = keep ? g * scale : 0  (g in the dtype of the sum, db in the dtype of the branch)
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const TA* __restrict__ g, TB* __restrict__ db, const long long* __restrict__ seed,
+                                                          long long n, unsigned thresh, float scale) {
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i0 >= n) return;
+  const DropSeed s = drop_seed(seed);
+  float v[8];
+  load8<TA>(g + i0, v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = drop_hash32((unsigned)(i0 + j), s.s0, s.s1) >= thresh ? v[j] * scale : 0.f;
+  store8<TB>(db + i0, v);
+}
+
+// out = dropout(act(h)); BWD: dh = keep ? g * scale * act'(h) : 0
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void act_dropout_kernel(const T* __restrict__ h, const T* __restrict__ g, T* __restrict__ out,
+                                                          const long long* __restrict__ seed, long long n, unsigned thresh, float scale,
+                                                          int act) {
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i0 >= n) return;
+  const DropSeed s = thresh ? drop_seed(seed) : DropSeed{0u, 0u};
+  float v[8], gv[8];
+  load8<T>(h + i0, v);
+  if (BWD) load8<T>(g + i0, gv);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool keep = thresh == 0u || drop_hash32((unsigned)(i0 + j), s.s0, s.s1) >= thresh;
+    const float y = BWD ? gv[j] * act_grad(v[j], act) : apply_act(v[j], act);
+    v[j] = keep ? y * scale : 0.f;
+  }
+  store8<T>(out + i0, v);
+}
+
+extern "C" {
+
+// out = a + dropout(b); a / out share a dtype, b may be bf16 next to fp32 a.  seed: one int64 on the device.
+int atri_add_dropout_fwd(const void* a, int a_bf16, const void* b, int b_bf16, void* out, const long long* seed, long long n,
+                         float p_drop, hipStream_t s) {
+  if (n <= 0) return 0;
+  if ((n & 7) || p_drop <= 0.f || p_drop >= 1.f || (a_bf16 && !b_bf16)) return (int)hipErrorInvalidValue;
+  const unsigned thresh = (unsigned)((double)p_drop * 4294967296.0);
+  const float scale = 1.0f / (1.0f - p_drop);
+  const dim3 grid((unsigned)((n / 8 + 255) / 256));
+  if (a_bf16)
+    hipLaunchKernelGGL((add_dropout_fwd_kernel<unsigned short, unsigned short>), grid, dim3(256), 0, s, (const unsigned short*)a,
+                       (const unsigned short*)b, (unsigned short*)out, seed, n, thresh, scale);
+  else if (b_bf16)
+    hipLaunchKernelGGL((add_dropout_fwd_kernel<float, unsigned short>), grid, dim3(256), 0, s, (const float*)a, (const unsigned short*)b,
+                       (float*)out, seed, n, thresh, scale);
+  else
+    hipLaunchKernelGGL((add_dropout_fwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, seed,
+                       n, thresh, scale);
+  return (int)hipGetLastError();
+}
+
+// db = keep ? g / (1 - p) : 0 with the mask of atri_add_dropout_fwd for the same seed.
+int atri_dropout_bwd(const void* g, int g_bf16, void* db, int db_bf16, const long long* seed, long long n, float p_drop, hipStream_t s) {
+  if (n <= 0) return 0;
+  if ((n & 7) || p_drop <= 0.f || p_drop >= 1.f || (g_bf16 && !db_bf16)) return (int)hipErrorInvalidValue;
+  const unsigned thresh = (unsigned)((double)p_drop * 4294967296.0);
+  const float scale = 1.0f / (1.0f - p_drop);
+  const dim3 grid((unsigned)((n / 8 + 255) / 256));
+  if (g_bf16)
+    hipLaunchKernelGGL((dropout_bwd_kernel<unsigned short, unsigned short>), grid, dim3(256), 0, s, (const unsigned short*)g,
+                       (unsigned short*)db, seed, n, thresh, scale);
+  else if (db_bf16)
+    hipLaunchKernelGGL((dropout_bwd_kernel<float, unsigned short>), grid, dim3(256), 0, s, (const float*)g, (unsigned short*)db, seed, n,
+                       thresh, scale);
+  else
+    hipLaunchKernelGGL((dropout_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)g, (float*)db, seed, n, thresh, scale);
+  return (int)hipGetLastError();
+}
+
+// forward (g == nullptr): out = dropout(act(h)); backward: out = dropout'(g) * act'(h).  p_drop == 0: no dropout.
+int atri_act_dropout(const void* h, const void* g, void* out, int is_bf16, const long long* seed, long long n, float p_drop, int act,
+                     hipStream_t s) {
+  if (n <= 0) return 0;
+  if ((n & 7) || p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && seed == nullptr)) return (int)hipErrorInvalidValue;
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  const float scale = 1.0f / (1.0f - p_drop);
+  const dim3 grid((unsigned)((n / 8 + 255) / 256));
+#define ATRI_ACT_DROPOUT(T, B) \
+  hipLaunchKernelGGL((act_dropout_kernel<T, B>), grid, dim3(256), 0, s, (const T*)h, (const T*)g, (T*)out, seed, n, thresh, scale, act)
+  if (is_bf16) {
+    if (g) ATRI_ACT_DROPOUT(unsigned short, true); else ATRI_ACT_DROPOUT(unsigned short, false);
+  } else {
+    if (g) ATRI_ACT_DROPOUT(float, true); else ATRI_ACT_DROPOUT(float, false);
+  }
+#undef ATRI_ACT_DROPOUT
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -326,9 +326,11 @@ __device__ __forceinline__ void ln_store8<unsigned short>(unsigned short* p, con
   *reinterpret_cast<short8*>(p) = pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
 }
 
-template <typename T, int LPR>
+// T: dtype of the rows; TO: dtype of the normalised rows (bf16 out of fp32 rows under autocast: the residual stream
+// stays fp32 and the next GEMM reads bf16, without a cast kernel in between).
+template <typename T, typename TO, int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ g,
-                                                     const float* __restrict__ b, T* __restrict__ y,
+                                                     const float* __restrict__ b, TO* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows,
                                                      float eps) {
   constexpr int D = LPR * 8, RPW = 64 / LPR;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   ln_load8<float>(b + sub * 8, bb);
 #pragma unroll
   for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * rstd * gg[j] + bb[j];
-  ln_store8<T>(y + (size_t)row * D + sub * 8, f);
+  ln_store8<TO>(y + (size_t)row * D + sub * 8, f);
   if (sub == 0) {
     mean_out[row] = mean;
     rstd_out[row] = rstd;
@@ -368,8 +370,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 
 // dx for every row plus per-workgroup partial sums of dgamma / dbeta ([gridDim.x][2][D]); each workgroup walks
 // rows_per_block rows so the partial buffer stays small.
-template <typename T, int LPR>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+// T: dtype of x and dx; TG: dtype of the incoming gradient (that of the forward's output).
+template <typename T, typename TG, int LPR>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const TG* __restrict__ dy,
                                                      const float* __restrict__ g, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, T* __restrict__ dx,
                                                      float* __restrict__ partial, int rows, int rows_per_block) {
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
     float mean = 0.f, rstd = 0.f;
     if (live) {
       ln_load8<T>(x + (size_t)row * D + sub * 8, xv);
-      ln_load8<T>(dy + (size_t)row * D + sub * 8, dv);
+      ln_load8<TG>(dy + (size_t)row * D + sub * 8, dv);
       mean = mean_in[row];
       rstd = rstd_in[row];
     }
@@ -435,17 +438,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
 }
 
 namespace {
-template <typename T, int LPR>
+template <typename T, typename TO, int LPR>
 void ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows, float eps,
                    hipStream_t s) {
   constexpr int RPB = 4 * (64 / LPR);
-  hipLaunchKernelGGL((ln_fwd_kernel<T, LPR>), dim3((rows + RPB - 1) / RPB), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean,
+  hipLaunchKernelGGL((ln_fwd_kernel<T, TO, LPR>), dim3((rows + RPB - 1) / RPB), dim3(256), 0, s, (const T*)x, g, b, (TO*)y, mean,
                      rstd, rows, eps);
 }
-template <typename T, int LPR>
+template <typename T, typename TG, int LPR>
 void ln_bwd_launch(const void* x, const void* dy, const float* g, const float* mean, const float* rstd, void* dx,
                    float* partial, int rows, int rows_per_block, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL((ln_bwd_kernel<T, LPR>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const T*)dy, g, mean, rstd, (T*)dx,
+  hipLaunchKernelGGL((ln_bwd_kernel<T, TG, LPR>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const TG*)dy, g, mean, rstd, (T*)dx,
                      partial, rows, rows_per_block);
 }
 }  // namespace
@@ -627,12 +630,15 @@ int atri_colsum(const void* g, int is_bf16, float* partial, float* out, int N, i
 }
 
 // y = LayerNorm(x) over the last dimension D in {64, 128, 256, 512}; mean / rstd [rows] are saved for the backward pass.
-int atri_ln_fwd(const void* x, int is_bf16, const float* g, const float* b, void* y, float* mean, float* rstd, int rows, int D,
-                float eps, hipStream_t s) {
+// is_bf16: dtype of x; out_bf16: dtype of y (fp32 rows may be written as bf16, not the other way round).
+int atri_ln_fwd(const void* x, int is_bf16, const float* g, const float* b, void* y, int out_bf16, float* mean, float* rstd,
+                int rows, int D, float eps, hipStream_t s) {
   if (rows <= 0) return 0;
-#define ATRI_LN_FWD(LPR)                                                                      \
-  if (is_bf16) ln_fwd_launch<unsigned short, LPR>(x, g, b, y, mean, rstd, rows, eps, s);      \
-  else ln_fwd_launch<float, LPR>(x, g, b, y, mean, rstd, rows, eps, s)
+  if (is_bf16 && !out_bf16) return (int)hipErrorInvalidValue;
+#define ATRI_LN_FWD(LPR)                                                                                     \
+  if (is_bf16) ln_fwd_launch<unsigned short, unsigned short, LPR>(x, g, b, y, mean, rstd, rows, eps, s);     \
+  else if (out_bf16) ln_fwd_launch<float, unsigned short, LPR>(x, g, b, y, mean, rstd, rows, eps, s);        \
+  else ln_fwd_launch<float, float, LPR>(x, g, b, y, mean, rstd, rows, eps, s)
   switch (D) {
     case 64: ATRI_LN_FWD(8); break;
     case 128: ATRI_LN_FWD(16); break;
@@ -646,14 +652,17 @@ int atri_ln_fwd(const void* x, int is_bf16, const float* g, const float* b, void
 
 // dx, dgamma, dbeta of LayerNorm.  partial holds blocks * 2 * D floats with blocks = ceil(rows / rows_per_block);
 // rows_per_block must be a multiple of 32.
-int atri_ln_bwd(const void* x, const void* dy, int is_bf16, const float* g, const float* mean, const float* rstd, void* dx,
-                float* partial, float* dgamma, float* dbeta, int rows, int D, int rows_per_block, hipStream_t s) {
+// is_bf16: dtype of x and dx; dy_bf16: dtype of dy (that of the forward's output).
+int atri_ln_bwd(const void* x, const void* dy, int is_bf16, int dy_bf16, const float* g, const float* mean, const float* rstd,
+                void* dx, float* partial, float* dgamma, float* dbeta, int rows, int D, int rows_per_block, hipStream_t s) {
   if (rows <= 0) return 0;
   if (rows_per_block <= 0 || (rows_per_block & 31)) return (int)hipErrorInvalidValue;
+  if (is_bf16 && !dy_bf16) return (int)hipErrorInvalidValue;
   const int blocks = (rows + rows_per_block - 1) / rows_per_block;
-#define ATRI_LN_BWD(LPR)                                                                                        \
-  if (is_bf16) ln_bwd_launch<unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, s); \
-  else ln_bwd_launch<float, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, s)
+#define ATRI_LN_BWD(LPR)                                                                                                               \
+  if (is_bf16) ln_bwd_launch<unsigned short, unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, s); \
+  else if (dy_bf16) ln_bwd_launch<float, unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, s);     \
+  else ln_bwd_launch<float, float, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, s)
   switch (D) {
     case 64: ATRI_LN_BWD(8); break;
     case 128: ATRI_LN_BWD(16); break;

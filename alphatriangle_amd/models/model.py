@@ -366,8 +366,10 @@ def _linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | Non
 class _LayerNormFn(torch.autograd.Function):
     """LayerNorm over the last dimension through the learner's HIP kernels (``ops.hip_learner.layer_norm_*``).
 
-    Rows keep their dtype: under autocast the bf16 activations are normalised with fp32 statistics and come out as
-    bf16, where torch's autocast policy would run the op in fp32 between two cast kernels.
+    bf16 rows are normalised with fp32 statistics and come out as bf16, where torch's autocast policy would run the op
+    in fp32 between two cast kernels.  fp32 rows under bf16 autocast (the residual stream of the encoder) come out as
+    bf16 as well: every consumer of a LayerNorm output in this network is a GEMM that autocast would feed with exactly
+    that cast, so the values are the same and the cast kernels (and their backward twins) are gone.
     """
 
     @staticmethod
@@ -376,7 +378,10 @@ class _LayerNormFn(torch.autograd.Function):
 
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         w32, b32 = weight.float().contiguous(), bias.float().contiguous()
-        y, mean, rstd = hip_learner.layer_norm_forward(x2, w32, b32, eps)
+        out_dtype = x2.dtype
+        if x2.dtype == torch.float32 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            out_dtype = torch.bfloat16
+        y, mean, rstd = hip_learner.layer_norm_forward(x2, w32, b32, eps, out_dtype)
         ctx.save_for_backward(x2, w32, mean, rstd)
         ctx.shape = x.shape
         return y.view(x.shape)
@@ -386,7 +391,10 @@ class _LayerNormFn(torch.autograd.Function):
         from ..ops import hip_learner
 
         x2, w32, mean, rstd = ctx.saved_tensors
-        dy2 = grad_out.reshape(x2.shape).to(x2.dtype).contiguous()
+        dy2 = grad_out.reshape(x2.shape)
+        if dy2.dtype != torch.bfloat16 or x2.dtype != torch.float32:  # bf16 gradients of fp32 rows are read as they are
+            dy2 = dy2.to(x2.dtype)
+        dy2 = dy2.contiguous()
         dx, dg, db = hip_learner.layer_norm_backward(x2, dy2, w32, mean, rstd)
         return dx.view(ctx.shape), dg, db, None
 
@@ -435,6 +443,49 @@ class _FusedAttention(torch.autograd.Function):
         return dqkv, None, None
 
 
+class _AddDropout(torch.autograd.Function):
+    """``a + dropout(b, p)`` in one launch (``ops.hip_learner.add_dropout_*``): the residual adds of the encoder layer.
+    The keep mask is a hash of a device-side seed and the element index, recomputed in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, a: torch.Tensor, b: torch.Tensor, p_drop: float) -> torch.Tensor:  # noqa: ANN001
+        from ..ops import hip_learner
+
+        out, seed = hip_learner.add_dropout_forward(a, b, p_drop)
+        ctx.save_for_backward(seed)
+        ctx.p_drop, ctx.b_dtype = p_drop, b.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        (seed,) = ctx.saved_tensors
+        g = grad_out.contiguous()
+        return g, hip_learner.dropout_backward(g, seed, ctx.p_drop, ctx.b_dtype), None
+
+
+class _ActDropout(torch.autograd.Function):
+    """``dropout(act(h), p)`` in one launch forward and one backward (``ops.hip_learner.act_dropout_*``)."""
+
+    @staticmethod
+    def forward(ctx, h: torch.Tensor, p_drop: float, act_id: int) -> torch.Tensor:  # noqa: ANN001
+        from ..ops import hip_learner
+
+        h = h.contiguous()
+        out, seed = hip_learner.act_dropout_forward(h, p_drop, act_id)
+        ctx.save_for_backward(h, seed if seed is not None else h.new_empty(0))
+        ctx.p_drop, ctx.act_id = p_drop, act_id
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        h, seed = ctx.saved_tensors
+        return hip_learner.act_dropout_backward(h, grad_out, seed if ctx.p_drop > 0 else None, ctx.p_drop, ctx.act_id), None, None
+
+
 class EncoderLayer(nn.TransformerEncoderLayer):
     """``nn.TransformerEncoderLayer`` (same sub-modules, same ``state_dict`` keys) with a learner fast path.
 
@@ -470,9 +521,27 @@ class EncoderLayer(nn.TransformerEncoderLayer):
         y = self.norm1(src)
         qkv = _linear_rows(y, attn.in_proj_weight, attn.in_proj_bias)  # [L, B, 3D]
         ctx = self._attention(qkv, seq, batch, dim, heads)
-        x = src + self.dropout1(_linear_rows(ctx, attn.out_proj.weight, attn.out_proj.bias))
-        hidden = self.dropout(self.activation(_linear_rows(self.norm2(x), self.linear1.weight, self.linear1.bias)))
-        return x + self.dropout2(_linear_rows(hidden, self.linear2.weight, self.linear2.bias))
+        x = self._add_dropout(src, _linear_rows(ctx, attn.out_proj.weight, attn.out_proj.bias), self.dropout1)
+        hidden = self._act_dropout(_linear_rows(self.norm2(x), self.linear1.weight, self.linear1.bias))
+        return self._add_dropout(x, _linear_rows(hidden, self.linear2.weight, self.linear2.bias), self.dropout2)
+
+    fused_dropout = True  # dropout fused with the residual adds / the FFN activation on the GPU (False: stock modules)
+
+    def _add_dropout(self, a: torch.Tensor, b: torch.Tensor, drop: nn.Dropout) -> torch.Tensor:
+        from ..ops import hip_learner
+
+        if self.fused_dropout and self.training and 0.0 < drop.p < 1.0 and hip_learner.add_dropout_supported(a, b):
+            return _AddDropout.apply(a, b, float(drop.p))
+        return a + drop(b)
+
+    def _act_dropout(self, h: torch.Tensor) -> torch.Tensor:
+        from ..ops import hip_learner
+
+        act_id = {torch.nn.functional.relu: 1, torch.nn.functional.gelu: 2}.get(self.activation)
+        p = float(self.dropout.p) if self.training else 0.0
+        if self.fused_dropout and act_id is not None and 0.0 <= p < 1.0 and hip_learner.act_dropout_supported(h):
+            return _ActDropout.apply(h, p, act_id)
+        return self.dropout(self.activation(h))
 
 
     fused_attention = True  # one-launch HIP attention where it applies; False keeps the batched-GEMM formulation

@@ -107,29 +107,91 @@ def colsum(g: torch.Tensor) -> torch.Tensor:
 LN_WIDTHS = (64, 128, 256, 512)
 
 
-def layer_norm_forward(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """``y, mean, rstd`` of LayerNorm over the last dimension of a contiguous ``[rows, D]`` bf16 / fp32 matrix."""
+def layer_norm_forward(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
+                       out_dtype: torch.dtype | None = None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``y, mean, rstd`` of LayerNorm over the last dimension of a contiguous ``[rows, D]`` bf16 / fp32 matrix.
+
+    ``out_dtype=torch.bfloat16`` with fp32 rows writes the normalised rows as bf16 (what an autocast GEMM would cast them
+    to anyway).
+    """
     rows, d = x2.shape
-    y = torch.empty_like(x2)
+    out_dtype = x2.dtype if out_dtype is None else out_dtype
+    if x2.dtype == torch.bfloat16 and out_dtype != torch.bfloat16:
+        raise ValueError("bf16 rows are normalised to bf16")
+    y = torch.empty(rows, d, dtype=out_dtype, device=x2.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
     hb.call("atri_ln_fwd", hb.ptr(x2), hb.i32(1 if x2.dtype == torch.bfloat16 else 0), hb.ptr(weight), hb.ptr(bias), hb.ptr(y),
-            hb.ptr(mean), hb.ptr(rstd), hb.i32(rows), hb.i32(d), hb.f32(eps))
+            hb.i32(1 if out_dtype == torch.bfloat16 else 0), hb.ptr(mean), hb.ptr(rstd), hb.i32(rows), hb.i32(d), hb.f32(eps))
     return y, mean, rstd
 
 
 def layer_norm_backward(x2: torch.Tensor, dy2: torch.Tensor, weight: torch.Tensor, mean: torch.Tensor,
                         rstd: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """``dx [rows, D]`` (dtype of x), ``dgamma [D]``, ``dbeta [D]`` (fp32)."""
+    """``dx [rows, D]`` (dtype of x), ``dgamma [D]``, ``dbeta [D]`` (fp32); ``dy2`` in the dtype of x or, for fp32 rows, bf16."""
     rows, d = x2.shape
     rows_per_block = max(32, (rows + 511) // 512 + 31 & ~31)  # about 500 workgroups, whole 32-row passes
     blocks = (rows + rows_per_block - 1) // rows_per_block
     dx = torch.empty_like(x2)
     partial = torch.empty(blocks * 2 * d, dtype=torch.float32, device=x2.device)
     dgb = torch.empty(2 * d, dtype=torch.float32, device=x2.device)
-    hb.call("atri_ln_bwd", hb.ptr(x2), hb.ptr(dy2), hb.i32(1 if x2.dtype == torch.bfloat16 else 0), hb.ptr(weight), hb.ptr(mean),
-            hb.ptr(rstd), hb.ptr(dx), hb.ptr(partial), hb.ptr(dgb), hb.ptr(dgb[d:]), hb.i32(rows), hb.i32(d), hb.i32(rows_per_block))
+    hb.call("atri_ln_bwd", hb.ptr(x2), hb.ptr(dy2), hb.i32(1 if x2.dtype == torch.bfloat16 else 0),
+            hb.i32(1 if dy2.dtype == torch.bfloat16 else 0), hb.ptr(weight), hb.ptr(mean), hb.ptr(rstd), hb.ptr(dx), hb.ptr(partial),
+            hb.ptr(dgb), hb.ptr(dgb[d:]), hb.i32(rows), hb.i32(d), hb.i32(rows_per_block))
     return dx, dgb[:d], dgb[d:]
+
+
+# ---------------------------------------------------------------- dropout fused with its neighbours
+def _drop_seed(device: torch.device) -> torch.Tensor:
+    """One int64 on the device from torch's generator: ``torch.manual_seed`` governs it, and a captured step draws a
+    new one on every replay."""
+    return torch.randint(0, 2**62, (1,), dtype=torch.int64, device=device)
+
+
+def add_dropout_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
+    ok = (torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)
+    return bool(a.is_cuda and b.is_cuda and a.shape == b.shape and (a.dtype, b.dtype) in ok and a.numel() % 8 == 0 and a.numel() > 0)
+
+
+def add_dropout_forward(a: torch.Tensor, b: torch.Tensor, p_drop: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """``a + dropout(b, p)`` in the dtype of ``a`` and the seed of its keep mask (``0 < p < 1``)."""
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    seed = _drop_seed(a.device)
+    hb.call("atri_add_dropout_fwd", hb.ptr(a), hb.i32(1 if a.dtype == torch.bfloat16 else 0), hb.ptr(b),
+            hb.i32(1 if b.dtype == torch.bfloat16 else 0), hb.ptr(out), hb.ptr(seed), hb.i64(a.numel()), hb.f32(p_drop))
+    return out, seed
+
+
+def dropout_backward(g: torch.Tensor, seed: torch.Tensor, p_drop: float, dtype: torch.dtype) -> torch.Tensor:
+    """Gradient of the dropped branch of :func:`add_dropout_forward` (``dtype``: that branch's dtype)."""
+    g = g.contiguous()
+    db = torch.empty(g.shape, dtype=dtype, device=g.device)
+    hb.call("atri_dropout_bwd", hb.ptr(g), hb.i32(1 if g.dtype == torch.bfloat16 else 0), hb.ptr(db),
+            hb.i32(1 if dtype == torch.bfloat16 else 0), hb.ptr(seed), hb.i64(g.numel()), hb.f32(p_drop))
+    return db
+
+
+def act_dropout_supported(h: torch.Tensor) -> bool:
+    return bool(h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.numel() % 8 == 0 and h.numel() > 0)
+
+
+def act_dropout_forward(h: torch.Tensor, p_drop: float, act_id: int) -> tuple[torch.Tensor, torch.Tensor | None]:
+    """``dropout(act(h), p)`` (``p`` may be 0) and the seed of the keep mask."""
+    h = h.contiguous()
+    out = torch.empty_like(h)
+    seed = _drop_seed(h.device) if p_drop > 0 else None
+    hb.call("atri_act_dropout", hb.ptr(h), hb.ptr(None), hb.ptr(out), hb.i32(1 if h.dtype == torch.bfloat16 else 0), hb.ptr(seed),
+            hb.i64(h.numel()), hb.f32(p_drop), hb.i32(act_id))
+    return out, seed
+
+
+def act_dropout_backward(h: torch.Tensor, g: torch.Tensor, seed: torch.Tensor | None, p_drop: float, act_id: int) -> torch.Tensor:
+    g = g.to(h.dtype).contiguous()
+    dh = torch.empty_like(h)
+    hb.call("atri_act_dropout", hb.ptr(h), hb.ptr(g), hb.ptr(dh), hb.i32(1 if h.dtype == torch.bfloat16 else 0), hb.ptr(seed),
+            hb.i64(h.numel()), hb.f32(p_drop), hb.i32(act_id))
+    return dh
 
 
 # ---------------------------------------------------------------- prioritized replay tree

@@ -246,6 +246,37 @@ def test_layer_norm_kernels_match_torch(rows, d, dtype):
     assert torch.allclose(gb.float(), gbr, rtol=1e-3, atol=1e-3 * rows ** 0.5)
 
 
+@pytest.mark.parametrize("rows,d", [(30720, 128), (1000, 256)])
+def test_layer_norm_of_fp32_rows_under_bf16_autocast_emits_bf16(rows, d):
+    """Under bf16 autocast the LayerNorm of an fp32 residual stream comes out as bf16 - the values an autocast GEMM would
+    cast the fp32 result to - and its backward takes the bf16 gradient and returns an fp32 one."""
+    from alphatriangle_amd.models.model import FastLayerNorm
+
+    torch.manual_seed(rows)
+    dev = torch.device("cuda")
+    ln = FastLayerNorm(d).to(dev)
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.3)
+        ln.bias.normal_(0.0, 0.3)
+    x = (torch.randn(rows, d, device=dev) * 2.0 + 0.5).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ln(x)
+    assert y.dtype == torch.bfloat16
+    gy = torch.randn(rows, d, device=dev).bfloat16()
+    gx, gw, gb = torch.autograd.grad(y, [x, ln.weight, ln.bias], gy)
+    assert gx.dtype == torch.float32
+    xr = x.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (d,), ln.weight, ln.bias, ln.eps)
+    gxr, gwr, gbr = torch.autograd.grad(yr, [xr, ln.weight, ln.bias], gy.float())
+    # forward: one bf16 rounding of the fp32 result (the fp32 results of the two implementations differ by ~1e-6, which
+    # can flip a rounding tie: allow one bf16 step)
+    assert (y.float() - yr.bfloat16().float()).abs().max().item() <= 2 ** -7 * yr.abs().max().item()
+    assert (gx - gxr).abs().max().item() < 1e-4 * max(1.0, gxr.abs().max().item())
+    assert torch.allclose(gw, gwr, rtol=1e-3, atol=1e-3 * rows ** 0.5)
+    assert torch.allclose(gb, gbr, rtol=1e-3, atol=1e-3 * rows ** 0.5)
+    assert ln(x).dtype == torch.float32  # outside autocast the rows keep their dtype
+
+
 @pytest.mark.parametrize("c,b,h,w,k,p", [(128, 256, 8, 15, 3, 1), (1, 256, 8, 15, 3, 1), (32, 64, 8, 15, 3, 0), (16, 8, 12, 21, 5, 2),
                                          (64, 32, 5, 9, 3, 2)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -672,3 +703,96 @@ def test_patch_free_conv_gemms_match_torch_convolution(cin, cout, batch, h, w):
     print(f"[{cin}->{cout}, {batch} x {h}x{w}] forward {e_f:.2e}, weight gradient {e_w:.2e}, data gradient {e_x:.2e}")
     assert e_f < 2e-5 and e_w < 2e-5 and e_x < 2e-5
     assert d_x is not None or cout % 4 != 0
+
+
+def _flat_keep_mask(seed: int, n: int, p: float, device) -> torch.Tensor:
+    """Host re-statement of ``drop_hash32`` in csrc/hip/learner_fused_kernels.hip over flat element indices."""
+    m32 = 0xFFFFFFFF
+    s0, s1 = seed & m32, (seed >> 32) & m32
+    thresh = int(float(np.float32(p)) * 4294967296.0)
+    x = (torch.arange(n, device=device, dtype=torch.int64) * 0x9E3779B1 + s0) & m32
+    x = ((x ^ (x >> 16)) * 0x85EBCA6B) & m32
+    x = ((x ^ (x >> 13)) * 0xC2B2AE35) & m32
+    x = ((x ^ (x >> 16)) + s1) & m32
+    x = ((x ^ (x >> 15)) * 0x2C1B3C6D) & m32
+    x = x ^ (x >> 12)
+    return x >= thresh
+
+
+@pytest.mark.parametrize("da,db", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+def test_fused_residual_dropout_matches_its_definition(da, db):
+    """a + dropout(b) and its two gradients against the same arithmetic in PyTorch with the kernel's own keep mask."""
+    from alphatriangle_amd.models.model import _AddDropout
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    p = 0.1
+    a = torch.randn(120, 37, 128, device=dev).to(da).requires_grad_(True)
+    b = torch.randn(120, 37, 128, device=dev).to(db).requires_grad_(True)
+    assert hip_learner.add_dropout_supported(a, b)
+    out, seed = hip_learner.add_dropout_forward(a.detach(), b.detach(), p)
+    keep = _flat_keep_mask(int(seed.item()), a.numel(), p, dev).view(a.shape)
+    assert abs(1.0 - keep.double().mean().item() - p) < 0.01
+    scale = 1.0 / (1.0 - float(np.float32(p)))
+    ref = a.detach().float() + torch.where(keep, b.detach().float() * scale, torch.zeros((), device=dev))
+    assert out.dtype == da and (out.float() - ref.to(da).float()).abs().max().item() <= (0 if da == torch.float32 else 2 ** -6 * ref.abs().max().item())
+    g = torch.randn_like(out)
+    gb = hip_learner.dropout_backward(g, seed, p, db)
+    gb_ref = torch.where(keep, g.float() * scale, torch.zeros((), device=dev)).to(db)
+    assert gb.dtype == db and torch.equal(gb, gb_ref)
+    # through autograd: the gradient of a is the incoming gradient, that of b is masked and scaled
+    torch.manual_seed(11)
+    y = _AddDropout.apply(a, b, p)
+    ga, gb2 = torch.autograd.grad(y, [a, b], g)
+    assert torch.equal(ga, g) and gb2.dtype == db
+    assert abs((gb2 == 0).double().mean().item() - p) < 0.01
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act_id,p", [(1, 0.1), (2, 0.1), (1, 0.0)])
+def test_fused_activation_dropout_matches_its_definition(dtype, act_id, p):
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(5)
+    dev = torch.device("cuda")
+    h = (torch.randn(120, 19, 256, device=dev) * 1.5).to(dtype)
+    out, seed = hip_learner.act_dropout_forward(h, p, act_id)
+    hd = h.double().requires_grad_(True)
+    act = torch.relu(hd) if act_id == 1 else torch.nn.functional.gelu(hd)
+    if p > 0:
+        keep = _flat_keep_mask(int(seed.item()), h.numel(), p, dev).view(h.shape)
+        ref = torch.where(keep, act / (1.0 - float(np.float32(p))), torch.zeros((), device=dev, dtype=torch.float64))
+    else:
+        assert seed is None
+        ref = act
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert (out.double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    g = torch.randn_like(h)
+    dh = hip_learner.act_dropout_backward(h, g, seed, p, act_id)
+    (ref * g.double()).sum().backward()
+    assert (dh.double() - hd.grad).abs().max().item() < tol * max(1.0, hd.grad.abs().max().item())
+
+
+def test_encoder_layer_with_fused_dropout_trains_like_the_stock_modules_in_eval_and_differs_only_by_its_masks():
+    """Evaluation mode: identical outputs with and without the fused dropout ops.  Training mode: the layer runs, the
+    fused path really drops (outputs differ between two calls) and gradients reach every parameter."""
+    from alphatriangle_amd.models.model import EncoderLayer
+
+    torch.manual_seed(9)
+    dev = torch.device("cuda")
+    layer = EncoderLayer(128, 4, 256, dropout=0.1, activation="relu", norm_first=True).to(dev)
+    x = torch.randn(120, 16, 128, device=dev)
+    layer.eval()
+    with torch.no_grad():
+        layer.fused_dropout = True
+        y1 = layer(x)
+        layer.fused_dropout = False
+        y2 = layer(x)
+    assert (y1 - y2).abs().max().item() < 1e-5
+    layer.train()
+    layer.fused_dropout = True
+    ya, yb = layer(x), layer(x)
+    assert (ya - yb).abs().max().item() > 1e-3
+    ya.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
