@@ -13,7 +13,8 @@ Layer -> kernel map (default config, B leaves, HW = 120 tokens):
                                          else conv_first_kernel (VALU, memory bound)
   residual blocks (128 channels)         rowconv_kernel<PAIR>: both convolutions in one launch, intermediate in LDS
   conv stem 1.., residual convs          rowconv_kernel (boards up to 8x15: halo tile in LDS, one sample per
-                                         workgroup, coalesced write-back) else tile_gemm_kernel taps=9
+                                         workgroup, coalesced write-back), flatconv_kernel (larger boards with
+                                         H * (W + 1) <= 320: flat pixel run in LDS) else tile_gemm_kernel taps=9
   1x1 projections, QKV, out-proj, FFN    tile_gemm_kernel taps=1  (+LayerNorm prologue,
                                          residual / activation / positional epilogue)
   4-head attention                       attention_kernel         (MFMA, softmax in registers)
@@ -490,6 +491,13 @@ class InferenceEngine:
                     hb.ptr(dst), hb.i32(rows // self.HW), hb.i32(self.H), hb.i32(self.W), hb.i32(layer.cin), hb.i32(layer.cout),
                     hb.i32(layer.act), hb.i32(layer.n_blocks))
             return
+        if (conv and layer.taps == 9 and self.use_rowconv and not out_f32 and out_stride is None and layer.ln_g is None
+                and layer.n_blocks == 1 and self._flat_ok(layer.cin, layer.cout)):
+            # flat-tiled one-sample-per-workgroup conv for boards above 8x15 (csrc/hip/flatconv_kernels.hip)
+            hb.call("atri_flatconv", hb.ptr(src), hb.ptr(layer.w), hb.ptr(layer.bias), hb.ptr(residual), hb.ptr(layer.post_add),
+                    hb.ptr(dst), hb.i32(rows // self.HW), hb.i32(self.H), hb.i32(self.W), hb.i32(layer.cin), hb.i32(layer.cout),
+                    hb.i32(layer.act))
+            return
         if conv:
             hw, h, w, rpw = self.HW, self.H, self.W, self.rows_per_wg
         else:
@@ -505,10 +513,17 @@ class InferenceEngine:
             hb.i32(out_stride if out_stride is not None else layer.cout), hb.i32(layer.n_blocks), hb.f32(layer.ln_eps),
         )
 
+    def _flat_ok(self, cin: int, cout: int) -> bool:
+        """The flat-tile conv kernel serves this layer: a board the 8x15 halo-tile kernel refuses, H * (W + 1) <= 320."""
+        if self.H <= 8 and self.W <= 15:
+            return False
+        return bool(hb.lib().atri_flatconv_supported(int(self.H), int(self.W), int(cin), int(cout)))
+
     def _pair_ok(self, l1: _GemmLayer, l2: _GemmLayer) -> bool:
-        """Both convolutions of a residual block fit the fused block kernel (8x15 boards, 128 channels, same activation)."""
+        """Both convolutions of a residual block fit a fused block kernel (128 channels, same activation; the halo-tile
+        kernel up to 8x15 boards, the flat-tile kernel above)."""
         return (
-            self.use_rowconv and self.fuse_res_blocks and self.H <= 8 and self.W <= 15
+            self.use_rowconv and self.fuse_res_blocks and ((self.H <= 8 and self.W <= 15) or self._flat_ok(128, 128))
             and l1.taps == 9 and l2.taps == 9 and l1.cin == l1.cout == l2.cin == l2.cout == 128
             and l1.act == l2.act and l1.post_add is None and l1.ln_g is None and l2.ln_g is None
         )
@@ -634,7 +649,8 @@ class InferenceEngine:
                 # whole residual block in one launch (the intermediate activation never leaves LDS)
                 l2 = body[li + 1][1]
                 dst = (cur + 1) % 3
-                hb.call("atri_rowconv_pair", hb.ptr(bufs[cur]), hb.ptr(layer.w), hb.ptr(layer.bias), hb.ptr(l2.w), hb.ptr(l2.bias),
+                pair_fn = "atri_rowconv_pair" if (self.H <= 8 and self.W <= 15) else "atri_flatconv_pair"
+                hb.call(pair_fn, hb.ptr(bufs[cur]), hb.ptr(layer.w), hb.ptr(layer.bias), hb.ptr(l2.w), hb.ptr(l2.bias),
                         hb.ptr(l2.post_add), hb.ptr(bufs[dst]), hb.i32(B), hb.i32(self.H), hb.i32(self.W), hb.i32(layer.cin),
                         hb.i32(layer.act))
                 cur = dst

@@ -316,6 +316,114 @@ def test_rowconv_matches_torch(cin, cout, residual, act, h, w):
     assert err <= 0.02 * scale + 0.03, f"max err {err} (scale {scale})"
 
 
+@pytest.mark.parametrize("cin,cout,residual,act,h,w", [(32, 64, False, 1, 12, 21), (64, 128, False, 2, 12, 21), (128, 128, True, 1, 12, 21),
+                                                       (128, 128, True, 1, 16, 15), (128, 128, False, 1, 9, 15), (128, 128, True, 1, 10, 19)])
+def test_flatconv_matches_torch(cin, cout, residual, act, h, w):
+    """flatconv_kernel (boards above 8x15: one flat pixel run per sample, 3 / 4 / 5 tiles per wave) against F.conv2d."""
+    from alphatriangle_amd.ops import hipbind as hb
+    from alphatriangle_amd.ops.inference import pack_gemm_weights
+
+    torch.manual_seed(17)
+    dev = _dev()
+    B, H, W = 5, h, w
+    HW = H * W
+    assert hb.lib().atri_flatconv_supported(H, W, cin, cout) == 1
+    x = _bf16_round(torch.randn(B, HW, cin, device=dev))
+    wt = _bf16_round(torch.randn(cout, cin, 3, 3, device=dev) * (1.0 / math.sqrt(cin * 9)))
+    bias = torch.randn(cout, device=dev)
+    res = _bf16_round(torch.randn(B, HW, cout, device=dev)) if residual else None
+    post = torch.randn(HW, cout, device=dev)
+    ref = F.conv2d(x.view(B, H, W, cin).permute(0, 3, 1, 2), wt, bias, padding=1).permute(0, 2, 3, 1).reshape(B, HW, cout)
+    if res is not None:
+        ref = ref + res
+    ref = F.relu(ref) if act == 1 else F.gelu(ref)
+    ref = ref + post[None]
+    packed, nb = pack_gemm_weights(wt.permute(2, 3, 1, 0).reshape(9, cin, cout), dev)
+    assert nb == 1
+    bpad = torch.zeros(128, device=dev)
+    bpad[:cout] = bias
+    out = torch.zeros(B * HW, cout, dtype=torch.bfloat16, device=dev)
+    xb = x.to(torch.bfloat16).contiguous()
+    rb = res.to(torch.bfloat16).contiguous() if res is not None else None
+    hb.call("atri_flatconv", hb.ptr(xb), hb.ptr(packed), hb.ptr(bpad), hb.ptr(rb), hb.ptr(post), hb.ptr(out),
+            hb.i32(B), hb.i32(H), hb.i32(W), hb.i32(cin), hb.i32(cout), hb.i32(act))
+    torch.cuda.synchronize()
+    got = out.float().view(B, HW, cout)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 0.02 * scale + 0.03, f"max err {err} (scale {scale})"
+
+
+@pytest.mark.parametrize("act,h,w", [(1, 12, 21), (2, 12, 21), (1, 11, 17)])
+def test_flatconv_pair_matches_two_launches_and_torch(act, h, w):
+    """flatconv_kernel<PAIR> (a residual block per launch, the intermediate stays in the flat LDS tile) against the
+    same two convolutions as separate launches and against the fp32 definition."""
+    from alphatriangle_amd.ops import hipbind as hb
+    from alphatriangle_amd.ops.inference import pack_gemm_weights
+
+    torch.manual_seed(19)
+    dev = _dev()
+    B, H, W, Cc = 7, h, w, 128
+    HW = H * W
+    x = _bf16_round(torch.randn(B, HW, Cc, device=dev))
+    w1 = _bf16_round(torch.randn(Cc, Cc, 3, 3, device=dev) * (1.0 / math.sqrt(Cc * 9)))
+    w2 = _bf16_round(torch.randn(Cc, Cc, 3, 3, device=dev) * (1.0 / math.sqrt(Cc * 9)))
+    b1, b2 = torch.randn(Cc, device=dev) * 0.3, torch.randn(Cc, device=dev) * 0.3
+    post = torch.randn(HW, Cc, device=dev)
+    fact = F.relu if act == 1 else F.gelu
+    xi = x.view(B, H, W, Cc).permute(0, 3, 1, 2)
+    mid = _bf16_round(fact(F.conv2d(xi, w1, b1, padding=1)))  # the kernel keeps the intermediate as bf16
+    ref = (fact(F.conv2d(mid, w2, b2, padding=1) + xi)).permute(0, 2, 3, 1).reshape(B, HW, Cc) + post[None]
+    p1, _ = pack_gemm_weights(w1.permute(2, 3, 1, 0).reshape(9, Cc, Cc), dev)
+    p2, _ = pack_gemm_weights(w2.permute(2, 3, 1, 0).reshape(9, Cc, Cc), dev)
+    xb = x.to(torch.bfloat16).contiguous()
+    fused = torch.zeros(B * HW, Cc, dtype=torch.bfloat16, device=dev)
+    hb.call("atri_flatconv_pair", hb.ptr(xb), hb.ptr(p1), hb.ptr(b1), hb.ptr(p2), hb.ptr(b2), hb.ptr(post), hb.ptr(fused),
+            hb.i32(B), hb.i32(H), hb.i32(W), hb.i32(Cc), hb.i32(act))
+    tmp = torch.zeros_like(fused)
+    two = torch.zeros_like(fused)
+    hb.call("atri_flatconv", hb.ptr(xb), hb.ptr(p1), hb.ptr(b1), hb.ptr(None), hb.ptr(None), hb.ptr(tmp),
+            hb.i32(B), hb.i32(H), hb.i32(W), hb.i32(Cc), hb.i32(Cc), hb.i32(act))
+    hb.call("atri_flatconv", hb.ptr(tmp), hb.ptr(p2), hb.ptr(b2), hb.ptr(xb), hb.ptr(post), hb.ptr(two),
+            hb.i32(B), hb.i32(H), hb.i32(W), hb.i32(Cc), hb.i32(Cc), hb.i32(act))
+    torch.cuda.synchronize()
+    if act == 1:
+        assert torch.equal(fused, two)  # rounding to bf16 commutes with ReLU
+    else:  # separate launches round the first convolution's output before AND after the activation
+        assert (fused.float() - two.float()).abs().max().item() < 0.06
+    got = fused.float().view(B, HW, Cc)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 0.02 * scale + 0.03, f"max err {err} (scale {scale})"
+
+
+def test_large_board_flat_and_tile_gemm_conv_paths_agree():
+    """The 12x21 preset through flatconv_kernel (stem layers, fused residual blocks) and through the generic tile kernel."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(23)
+    dev = _dev()
+    env, mc = EnvConfig.large(), ModelConfig.large_transformer()
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev, inference_dtype="bf16")
+    eng = net.engine
+    assert eng is not None and eng.use_rowconv
+    res_a = [l for k, l in eng.body_layers if k == "res_a"][0]
+    res_b = [l for k, l in eng.body_layers if k == "res_b"][0]
+    assert eng._flat_ok(128, 128) and eng._pair_ok(res_a, res_b)
+    B = 9
+    grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    l1, v1 = (t.clone() for t in eng.forward(grid, other))
+    eng.use_rowconv = False
+    try:
+        l2, v2 = (t.clone() for t in eng.forward(grid, other))
+    finally:
+        eng.use_rowconv = True
+    torch.cuda.synchronize()
+    assert (l1 - l2).abs().max().item() < 0.05
+    assert (v1 - v2).abs().max().item() < 0.1
+
+
 def test_rowconv_and_tile_gemm_paths_agree():
     from alphatriangle_amd.models.network import NeuralNetwork
 
