@@ -65,7 +65,7 @@ __device__ __forceinline__ void flatconv_mainloop(float4v (&acc)[TPW][4], const 
   }
 #pragma unroll
   for (int i = 0; i < kFlatAhead; ++i) av[i] = *reinterpret_cast<const short8*>(FLATCONV_ROW(i));
-#pragma unroll
+#pragma clang loop unroll(full)
   for (int i = 0; i < TOTAL; ++i) {
     const int s = i / TPW, t = i % TPW, wc = s % 3;
     __builtin_amdgcn_sched_barrier(0);
@@ -133,7 +133,9 @@ __global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs 
   const unsigned char* tile_base = smem + (tile0 * 16 + l15) * stride + q4 * 16;
   const bool active = h * 64 < a.Cout;  // wave-uniform: a 64-channel layer occupies the waves of half 0 only
   float4v acc[TPW][4];
-#pragma unroll
+  // one copy of the unrolled main loop, run twice for a pair: two copies exceed the unroller's size budget, which
+  // then leaves the tile loop rolled with its fragment addresses computed at run time
+#pragma unroll 1
   for (int stage = 0; stage < (PAIR ? 2 : 1); ++stage) {
     const unsigned short* wsrc = (PAIR && stage == 1) ? a.w2 : a.w;
     const float* bsrc = (PAIR && stage == 1) ? a.bias2 : a.bias;
