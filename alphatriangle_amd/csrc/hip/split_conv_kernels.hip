@@ -91,7 +91,7 @@ __device__ __forceinline__ void split_mainloop(float4v (&acc)[8][2], const unsig
     xh[i] = *reinterpret_cast<const short8*>(base_hi + SPLIT_ROW(i / NR, R0 + i % NR));
     xl[i] = *reinterpret_cast<const short8*>(base_lo + SPLIT_ROW(i / NR, R0 + i % NR));
   }
-#pragma unroll
+#pragma clang loop unroll(full)
   for (int i = 0; i < GROUPS * NR; ++i) {
     const int g = i / NR, r = R0 + i % NR, wc = g & 1, wn = wc ^ 1;
     __builtin_amdgcn_sched_barrier(0);
