@@ -28,7 +28,7 @@ struct FlatConvArgs {
   unsigned short* out;             // [B, HW, Cout] bf16
   const unsigned short* w2;        // PAIR: second convolution
   const float* bias2;
-  int B, H, W, P, HW, Cin, Cout, act, log2_cpr, rows, pmagic, wmagic;
+  int B, H, W, P, HW, Cin, Cout, act, log2_cpr, rows, pmagic, wmagic, full_groups;
   const int* live;                 // device row count (nullptr: B rows), see common.hpp
   long long* phase_clock;          // diagnostics (PROBE instantiation): workgroup `phase_block` stores the shader clock
   int phase_block;                 // at its phase boundaries
@@ -85,51 +85,20 @@ __device__ __forceinline__ void flatconv_mainloop(float4v (&acc)[TPW][4], const 
 }
 }  // namespace
 
-// PAIR: a whole residual block (alphatriangle/nn/model.py:40-59) per launch, 128 channels throughout; the skip
-// connection is read from the block input in memory during the write-back.
-template <int CIN, int TPW, bool PAIR, bool PROBE = false>
-__global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs a) {
 #define FLAT_PHASE(i)                                                                                  \
   if constexpr (PROBE) {                                                                               \
     if ((int)blockIdx.x == a.phase_block && threadIdx.x == 0) a.phase_clock[i] = clock64();             \
   }
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q4 = lane >> 4, l15 = lane & 15;
-  const int b = blockIdx.x;
-  if (b >= live_rows(a.live, a.B)) return;  // whole workgroup, before any barrier
+
+// The convolution(s) of one wave over its NT tiles starting at tile0, from the staged flat tile to the output staging
+// tile (every barrier of the workgroup between those two points is in here: waves with NT and NT - 1 tiles run
+// different instantiations and meet at the same barrier count).
+template <int CIN, int NT, bool PAIR, bool PROBE>
+__device__ __forceinline__ void flat_convs(const FlatConvArgs& a, unsigned char* smem, int tile0, int h, int lane) {
+  constexpr int TPW = NT;
   constexpr int stride = CIN * 2 + 32;
+  const int q4 = lane >> 4, l15 = lane & 15;
   const int H = a.H, W = a.W, P = a.P;
-  FLAT_PHASE(0);
-
-  // ---- stage the sample into the flat tile, zeros everywhere else; eight global loads in flight per thread ----
-  {
-    const int cmask = (1 << a.log2_cpr) - 1;
-    const int total = a.rows << a.log2_cpr;
-    const unsigned short* src = a.in + (size_t)b * a.HW * a.Cin;
-    for (int c0 = tid; c0 < total; c0 += kFlatThreads * 8) {
-      uint4 v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + i * kFlatThreads;
-        v[i] = make_uint4(0, 0, 0, 0);
-        const int rr = (c >> a.log2_cpr) - (P + 1);
-        const int y = (rr * a.pmagic) >> 16, x = rr - y * P;
-        if (c < total && rr >= 0 && y < H && x < W)
-          v[i] = *reinterpret_cast<const uint4*>(src + (size_t)(y * W + x) * a.Cin + (c & cmask) * 8);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + i * kFlatThreads;
-        if (c < total) *reinterpret_cast<uint4*>(smem + (c >> a.log2_cpr) * stride + (c & cmask) * 16) = v[i];
-      }
-    }
-  }
-  FLAT_PHASE(1);
-  __syncthreads();
-  FLAT_PHASE(2);
-
-  const int h = wave & 1, tile0 = (wave >> 1) * TPW;  // channel half, first tile of this wave
   const unsigned char* tile_base = smem + (tile0 * 16 + l15) * stride + q4 * 16;
   const bool active = h * 64 < a.Cout;  // wave-uniform: a 64-channel layer occupies the waves of half 0 only
   float4v acc[TPW][4];
@@ -210,6 +179,61 @@ __global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs 
     FLAT_PHASE(10);
   }
 
+}
+
+// PAIR: a whole residual block (alphatriangle/nn/model.py:40-59) per launch, 128 channels throughout; the skip
+// connection stays in the registers that staged the block input.
+template <int CIN, int TPW, bool PAIR, bool PROBE = false>
+__global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.x;
+  if (b >= live_rows(a.live, a.B)) return;  // whole workgroup, before any barrier
+  constexpr int stride = CIN * 2 + 32;
+  const int H = a.H, W = a.W, P = a.P;
+  FLAT_PHASE(0);
+
+  // ---- stage the sample into the flat tile: thread -> (pixel, 8-channel chunk) as in the write-back, all loads of a
+  // thread in flight at once (H * W <= 256 pixels: at most eight chunks per thread); rows that are no pixel (halo
+  // runs, spare column, overhang) are zero-filled while the loads are under way.  A residual block keeps the chunks
+  // in registers: they are its skip connection.
+  uint4 xin[8];
+  {
+    const int l2 = a.log2_cpr, cmask = (1 << l2) - 1;
+    const int total = a.HW << l2;
+    const unsigned short* src = a.in + (size_t)b * a.HW * a.Cin;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = min(tid + i * kFlatThreads, total - 1);
+      xin[i] = *reinterpret_cast<const uint4*>(src + (size_t)(c >> l2) * a.Cin + (c & cmask) * 8);
+    }
+    for (int c = tid; c < (a.rows << l2); c += kFlatThreads) {
+      const int r = c >> l2, rr = r - (P + 1);
+      const int y = (rr * a.pmagic) >> 16, x = rr - y * P;
+      if (!(rr >= 0 && y < H && x < W)) *reinterpret_cast<uint4*>(smem + r * stride + (c & cmask) * 16) = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + i * kFlatThreads;
+      if (c < total) {
+        const int pp = c >> l2;
+        const int y = (pp * a.wmagic) >> 16, x = pp - y * W;
+        *reinterpret_cast<uint4*>(smem + (y * P + x + P + 1) * stride + (c & cmask) * 16) = xin[i];
+      }
+    }
+  }
+  FLAT_PHASE(1);
+  __syncthreads();
+  FLAT_PHASE(2);
+
+  // channel half and tile quarter of this wave; the first `full_groups` quarters hold TPW tiles, the others TPW - 1
+  const int h = wave & 1, tq = wave >> 1;
+  if (tq < a.full_groups)  // wave-uniform
+    flat_convs<CIN, TPW, PAIR, PROBE>(a, smem, tq * TPW, h, lane);
+  else
+    flat_convs<CIN, TPW - 1, PAIR, PROBE>(a, smem, a.full_groups + tq * (TPW - 1), h, lane);
+
   // ---- coalesced write-back: thread -> (pixel, 8-channel chunk), whole rows per wave ----
   const int n_ch = min(128, a.Cout);
   int l2c = 0;
@@ -218,7 +242,10 @@ __global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs 
   const size_t gbase = (size_t)b * a.HW * a.Cout;
   for (int c0 = tid; c0 < chunks; c0 += kFlatThreads * 8) {
     short8 rv[8];
-    if (a.residual != nullptr) {
+    if (PAIR) {  // the skip connection is the block input: same (pixel, chunk) mapping as the staging, still in registers
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rv[i] = __builtin_bit_cast(short8, xin[i]);
+    } else if (a.residual != nullptr) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = min(c0 + i * kFlatThreads, chunks - 1);
@@ -235,7 +262,7 @@ __global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs 
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = bf16_to_float((unsigned short)hv[j]);
-      if (a.residual != nullptr) {
+      if (PAIR || a.residual != nullptr) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bf16_to_float((unsigned short)rv[i][j]);
       }
@@ -269,11 +296,12 @@ namespace {
 long long* g_flat_phase_clock = nullptr;
 int g_flat_phase_block = 0;
 
-// Tiles per wave for a board: ceil(H * (W + 1) / 16) tiles over four tile quarters; 0 = not served.
+int flat_tiles(int H, int W) { return (H * (W + 1) + 15) / 16; }
+
+// Largest tile count of a wave for a board: ceil(H * (W + 1) / 16) tiles over four tile quarters; 0 = not served.
 int flat_tiles_per_wave(int H, int W) {
-  if (H < 1 || W < 1) return 0;
-  const int tiles = (H * (W + 1) + 15) / 16;
-  const int tpw = (tiles + 3) / 4;
+  if (H < 1 || W < 1 || H * W > 256) return 0;  // staging and write-back move a sample in one pass of 8 chunks per thread
+  const int tpw = (flat_tiles(H, W) + 3) / 4;
   return tpw <= 3 ? 3 : (tpw <= 5 ? tpw : 0);
 }
 
@@ -305,7 +333,11 @@ int flat_fill_geometry(FlatConvArgs& a, int H, int W, int Cin, int tpw) {
   int l2 = 0;
   while ((1 << l2) < (Cin >> 3)) ++l2;
   a.log2_cpr = l2;
-  const int slots = 64 * tpw;       // flat positions covered by the 4 * tpw tiles
+  // tpw tiles for the first full_groups tile quarters, tpw - 1 for the others (a board of fewer than 4 * (tpw - 1)
+  // tiles - only possible at tpw = 3 - computes a few tiles of overhang)
+  const int tiles = flat_tiles(H, W) > 4 * (tpw - 1) ? flat_tiles(H, W) : 4 * (tpw - 1);
+  a.full_groups = tiles - 4 * (tpw - 1);
+  const int slots = 16 * tiles;     // flat positions covered by the tiles
   a.rows = slots + 2 * a.P + 2;     // + the halo runs in front and behind
   a.pmagic = 65536 / a.P + 1;
   a.wmagic = 65536 / W + 1;
