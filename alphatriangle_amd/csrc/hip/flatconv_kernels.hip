@@ -11,9 +11,12 @@
 //     tap is then a constant row offset (dy * P + dx) for EVERY pixel, so an MFMA tile is simply 16 consecutive flat
 //     positions: 12 x 22 = 264 positions make 17 tiles, against 24 tiles if every image row were padded to 32.
 //   * wave -> (64 of the 128 output channels, a quarter of the tiles): one 16-byte LDS fragment read feeds four
-//     MFMAs, which keeps the LDS pipe at half of what the matrix pipe asks for with eight waves on the CU.
+//     MFMAs, which keeps the LDS pipe at half of what the matrix pipe asks for with eight waves on the CU.  Tile
+//     counts that are no multiple of four are dealt out unevenly (17 tiles = 5 + 4 + 4 + 4): waves with one tile
+//     less run their own instantiation of the convolution code and meet the others at the same barriers.
 //   * Residual blocks run both convolutions in one launch; the first one's activated output goes from the
-//     accumulators back into the same flat tile (spare column and overhang written as zeros).
+//     accumulators back into the same flat tile (spare column and overhang written as zeros), and the skip
+//     connection stays in the registers that staged the block input (staging and write-back use one thread mapping).
 //   * The accumulators leave through an LDS transpose and whole 256-byte rows, as in conv_kernels.hip.
 #include "common.hpp"
 
