@@ -892,15 +892,16 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnCoreArgs a) {
   }
 }
 
-// LayerNorm1 + QKV projection + attention core of one sample per workgroup, for 129..256 tokens: Q, K and V never go to
-// memory.  Sixteen waves: wave (pair, octant) owns heads 2*pair and 2*pair + 1 for the 32 tokens of its octant.  It
+// LayerNorm1 + QKV projection + attention core of one (sample, head pair) per workgroup, for 129..256 tokens: Q, K and V
+// never go to memory.  Eight waves: wave `octant` owns heads 2*pair and 2*pair + 1 for the 32 tokens of its octant.  It
 // loads those rows straight into MFMA operand registers (no LDS tile), normalises them in registers once for both
 // heads (LayerNorm's affine part is folded into the weights by the host) and produces Q (kept), K and V^T of its
 // tokens.  The K / V^T operand images go through LDS lane-linearly - producer and consumer lanes hold identical
-// fragments, so the exchange is a conflict-free register dump of 128 KB - and after one barrier every wave runs its
+// fragments, so the exchange is a conflict-free register dump of 64 KB - and after one barrier every wave runs its
 // four (head, query tile) pairs like attn_core_kernel, reading the K / V^T fragments of all 256 key slots from LDS at
-// every use: 128 VGPRs, so the sixteen waves share the CU four to a SIMD and fill each other's
-// MFMA -> softmax -> MFMA dependency stalls.
+// every use: 128 VGPRs and 64 KB of LDS, so two workgroups share the CU, four waves to a SIMD, and the matrix-bound
+// projection phase of one overlaps the exp-bound softmax phase of the other (one 16-wave workgroup per sample, both
+// head pairs behind one barrier: 174 us per layer at 2048 samples of 252 tokens; this form: 158 us).
 struct QkvAttnArgs {
   const unsigned short* x;     // [B, HW, 128]
   const unsigned short* wqkv;  // packed, LayerNorm affine folded in, Q pre-scaled by log2(e)/sqrt(32)
@@ -909,7 +910,7 @@ struct QkvAttnArgs {
   int B, HW;
   float ln_eps;
 };
-constexpr int kQkvAttnLds = 4 * (16 + 16) * 1024;
+constexpr int kQkvAttnLds = 2 * (16 + 16) * 1024;
 
 template <bool SWAP, int MT>
 __device__ __forceinline__ void gemm_regs(float4v (&acc)[MT][2], const WFrags& w, const short8 (&xf)[MT][4]) {
@@ -941,8 +942,8 @@ __device__ __forceinline__ bool qkv_attn_tiles(const QkvAttnArgs& a, const short
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
     const int head = pair * 2 + hh;
-    const short8* kh = kimg + head * 16 * 64;
-    const short8* vh = vimg + head * 16 * 64;
+    const short8* kh = kimg + hh * 16 * 64;
+    const short8* vh = vimg + hh * 16 * 64;
     unsigned short* og = a.att + (size_t)b * HW * kD + head * 32 + q4 * 8;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -993,16 +994,16 @@ __device__ __forceinline__ bool qkv_attn_tiles(const QkvAttnArgs& a, const short
 }
 
 template <int KTF>
-__global__ __launch_bounds__(1024, 4) void qkv_attn_kernel(QkvAttnArgs a) {
+__global__ __launch_bounds__(512, 4) void qkv_attn_kernel(QkvAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pair = wave >> 3, oct = wave & 7;
+  const int pair = blockIdx.x & 1, oct = wave;
   const int q4 = lane >> 4, l15 = lane & 15;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x >> 1;
   const int HW = a.HW;
   const unsigned short* xg = a.x + (size_t)b * HW * kD;
-  short8* kimg = reinterpret_cast<short8*>(smem) + lane;              // [4 heads][16 kt][64]
-  short8* vimg = reinterpret_cast<short8*>(smem + 64 * 1024) + lane;  // [4 heads][8 kb][2 n][64]
+  short8* kimg = reinterpret_cast<short8*>(smem) + lane;              // [2 heads][16 kt][64]
+  short8* vimg = reinterpret_cast<short8*>(smem + 32 * 1024) + lane;  // [2 heads][8 kb][2 n][64]
 
   short8 xf[2][4];
 #pragma unroll
@@ -1055,7 +1056,7 @@ __global__ __launch_bounds__(1024, 4) void qkv_attn_kernel(QkvAttnArgs a) {
       }
       gemm_regs<false, 2>(acc, w, xf);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) kimg[(head * 16 + oct * 2 + t) * 64] = pack8(acc[t][0], acc[t][1]);
+      for (int t = 0; t < 2; ++t) kimg[(hh * 16 + oct * 2 + t) * 64] = pack8(acc[t][0], acc[t][1]);
     }
     load_wfrags(w, wq + (size_t)8 * 512);  // V weights
     {  // ---- V with swapped operands: acc[t][n][j] = V[token t*16 + 4 q4 + j][dim perm(l15, n)] -> V^T operand images
@@ -1069,7 +1070,7 @@ __global__ __launch_bounds__(1024, 4) void qkv_attn_kernel(QkvAttnArgs a) {
       }
       gemm_regs<true, 2>(acc, w, xf);
 #pragma unroll
-      for (int n = 0; n < 2; ++n) vimg[((head * 8 + oct) * 2 + n) * 64] = pack8(acc[0][n], acc[1][n]);
+      for (int n = 0; n < 2; ++n) vimg[((hh * 8 + oct) * 2 + n) * 64] = pack8(acc[0][n], acc[1][n]);
     }
     load_wfrags(w, wq);  // Q weights
     {  // ---- Q of these 32 tokens stays in registers
@@ -1373,8 +1374,8 @@ static int layer_rows_impl(const void* x, void* out, const void* wqkv, const flo
       attr2 = true;
     }
     QkvAttnArgs fa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, (unsigned short*)att, B, HW, ln1_eps};
-    if (HW > 240) hipLaunchKernelGGL(qkv_attn_kernel<15>, dim3(B), dim3(1024), kQkvAttnLds, stream, fa);
-    else hipLaunchKernelGGL(qkv_attn_kernel<-1>, dim3(B), dim3(1024), kQkvAttnLds, stream, fa);
+    if (HW > 240) hipLaunchKernelGGL(qkv_attn_kernel<15>, dim3(2 * B), dim3(512), kQkvAttnLds, stream, fa);
+    else hipLaunchKernelGGL(qkv_attn_kernel<-1>, dim3(2 * B), dim3(512), kQkvAttnLds, stream, fa);
   } else {
     QkvRowsArgs qa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, ln1_g, ln1_b, (unsigned short*)q,
                    (unsigned short*)k, (unsigned short*)vt, rows, HW, ln1_eps};
