@@ -317,7 +317,8 @@ def test_rowconv_matches_torch(cin, cout, residual, act, h, w):
 
 
 @pytest.mark.parametrize("cin,cout,residual,act,h,w", [(32, 64, False, 1, 12, 21), (64, 128, False, 2, 12, 21), (128, 128, True, 1, 12, 21),
-                                                       (128, 128, True, 1, 16, 15), (128, 128, False, 1, 9, 15), (128, 128, True, 1, 10, 19)])
+                                                       (128, 128, True, 1, 16, 15), (128, 128, False, 1, 9, 15), (128, 128, True, 1, 10, 19),
+                                                       (128, 128, True, 1, 9, 10), (64, 64, False, 1, 3, 40), (32, 128, False, 1, 16, 16)])
 def test_flatconv_matches_torch(cin, cout, residual, act, h, w):
     """flatconv_kernel (boards above 8x15: one flat pixel run per sample, 3 / 4 / 5 tiles per wave) against F.conv2d."""
     from alphatriangle_amd.ops import hipbind as hb
