@@ -909,6 +909,7 @@ struct QkvAttnArgs {
   unsigned short* att;         // [B, HW, 128]
   int B, HW;
   float ln_eps;
+  const int* live;             // device row count (nullptr: B rows), see common.hpp
 };
 constexpr int kQkvAttnLds = 2 * (16 + 16) * 1024;
 
@@ -1000,6 +1001,7 @@ __global__ __launch_bounds__(512, 4) void qkv_attn_kernel(QkvAttnArgs a) {
   const int pair = blockIdx.x & 1, oct = wave;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x >> 1;
+  if (b >= live_rows(a.live, a.B)) return;  // whole workgroup, before any barrier
   const int HW = a.HW;
   const unsigned short* xg = a.x + (size_t)b * HW * kD;
   short8* kimg = reinterpret_cast<short8*>(smem) + lane;              // [2 heads][16 kt][64]
@@ -1177,6 +1179,8 @@ struct ProjFfnRowsArgs {
   unsigned short* out;        // [rows, 128]
   int rows, act;
   float ln2_eps;
+  const int* live;            // device sample count (nullptr: all rows): only the rows of the first *live samples exist
+  int B, HW;
 };
 
 template <int HALVES>
@@ -1187,7 +1191,9 @@ __global__ __launch_bounds__(256, 2) void proj_ffn_rows_kernel(ProjFfnRowsArgs a
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int row0 = blockIdx.x * kRows;
-  const int nrows = min(kRows, a.rows - row0);
+  const int rows = live_rows(a.live, a.B) * a.HW;
+  if (row0 >= rows) return;  // whole workgroup, before any barrier
+  const int nrows = min(kRows, rows - row0);
   const int ch0 = wave * 32 + q4 * 8;
   WFrags w;
   load_wfrags(w, reinterpret_cast<const short8*>(a.wo) + (size_t)wave * 128 + lane);
@@ -1373,7 +1379,8 @@ static int layer_rows_impl(const void* x, void* out, const void* wqkv, const flo
       (void)hipFuncSetAttribute((const void*)qkv_attn_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, kQkvAttnLds);
       attr2 = true;
     }
-    QkvAttnArgs fa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, (unsigned short*)att, B, HW, ln1_eps};
+    QkvAttnArgs fa{(const unsigned short*)x, (const unsigned short*)wqkv, bqkv, (unsigned short*)att, B, HW, ln1_eps,
+                   live_count_ptr()};
     if (HW > 240) hipLaunchKernelGGL(qkv_attn_kernel<15>, dim3(2 * B), dim3(512), kQkvAttnLds, stream, fa);
     else hipLaunchKernelGGL(qkv_attn_kernel<-1>, dim3(2 * B), dim3(512), kQkvAttnLds, stream, fa);
   } else {
@@ -1385,7 +1392,7 @@ static int layer_rows_impl(const void* x, void* out, const void* wqkv, const flo
   }
   ProjFfnRowsArgs pa{(const unsigned short*)att, (const unsigned short*)x, (const unsigned short*)wo, bo,
                      (const unsigned short*)w1, b1, (const unsigned short*)w2, b2, ln2_g, ln2_b, (unsigned short*)out,
-                     rows, act, ln2_eps};
+                     rows, act, ln2_eps, live_count_ptr(), B, HW};
   switch (F >> 7) {
     case 1: return launch_proj_ffn<1>(pa, stream);
     case 2: return launch_proj_ffn<2>(pa, stream);

@@ -425,6 +425,31 @@ def test_large_board_flat_and_tile_gemm_conv_paths_agree():
     assert (v1 - v2).abs().max().item() < 0.1
 
 
+@pytest.mark.parametrize("preset", ["default", "large"])
+def test_live_count_rows_match_the_full_batch(preset):
+    """A device-side live count makes the batch kernels skip the rows behind it; the rows in front of it must come out
+    exactly as in the full batch (bf16 engine; the 12x21 preset goes through the flat-tile conv and row-tiled layer kernels)."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(29)
+    dev = _dev()
+    env = EnvConfig.large() if preset == "large" else EnvConfig()
+    mc = ModelConfig.large_transformer() if preset == "large" else ModelConfig()
+    eng = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev, inference_dtype="bf16").engine
+    assert eng is not None
+    B, n = 23, 9
+    grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    lf, vf = (t.clone() for t in eng.forward(grid, other))
+    live = torch.tensor([n], dtype=torch.int32, device=dev)
+    lp, vp = (t.clone() for t in eng.forward(grid, other, live=live))
+    torch.cuda.synchronize()
+    assert torch.equal(lp[:n], lf[:n]) and torch.equal(vp[:n], vf[:n])
+    lz, vz = (t.clone() for t in eng.forward(grid, other, live=torch.zeros(1, dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    assert torch.isfinite(lz).all() and torch.isfinite(vz).all()  # nothing ran, nothing was corrupted
+
+
 def test_rowconv_and_tile_gemm_paths_agree():
     from alphatriangle_amd.models.network import NeuralNetwork
 
