@@ -17,6 +17,8 @@
 //   * Residual blocks run both convolutions in one launch; the first one's activated output goes from the
 //     accumulators back into the same flat tile (spare column and overhang written as zeros), and the skip
 //     connection stays in the registers that staged the block input (staging and write-back use one thread mapping).
+//   * The conv stem is one launch as well: the single-channel first layer is evaluated while staging, the
+//     32 -> 64 -> 128 pair keeps its 64-channel intermediate in a second flat tile.
 //   * The accumulators leave through an LDS transpose and whole 256-byte rows, as in conv_kernels.hip.
 #include "common.hpp"
 
@@ -35,6 +37,12 @@ struct FlatConvArgs {
   const int* live;                 // device row count (nullptr: B rows), see common.hpp
   long long* phase_clock;          // diagnostics (PROBE instantiation): workgroup `phase_block` stores the shader clock
   int phase_block;                 // at its phase boundaries
+  // FIRST instantiation only (conv stem in one launch): the network's first layer (1 input channel, 3x3) is evaluated
+  // while staging, its output feeds the pair CIN -> CIN2 -> Cout whose intermediate lives in a second flat tile
+  const float* grid;     // [B, HW] f32 board planes
+  const float* w_first;  // [9][CIN] f32 (BatchNorm folded)
+  const float* b_first;  // [CIN]
+  int tile2_off, aux_off, plane_w;
 };
 
 namespace {
@@ -96,21 +104,25 @@ __device__ __forceinline__ void flatconv_mainloop(float4v (&acc)[TPW][4], const 
 // The convolution(s) of one wave over its NT tiles starting at tile0, from the staged flat tile to the output staging
 // tile (every barrier of the workgroup between those two points is in here: waves with NT and NT - 1 tiles run
 // different instantiations and meet at the same barrier count).
-template <int CIN, int NT, bool PAIR, bool PROBE>
+template <int CIN, int NT, bool PAIR, bool PROBE, int CIN2 = CIN>
 __device__ __forceinline__ void flat_convs(const FlatConvArgs& a, unsigned char* smem, int tile0, int h, int lane) {
   constexpr int TPW = NT;
-  constexpr int stride = CIN * 2 + 32;
+  constexpr int stride = CIN * 2 + 32, stride2 = CIN2 * 2 + 32;
   const int q4 = lane >> 4, l15 = lane & 15;
   const int H = a.H, W = a.W, P = a.P;
+  // a pair of two widths (the conv stem) keeps its intermediate in a second tile; a residual block writes it in place
+  unsigned char* tile2 = smem + (CIN2 != CIN ? a.tile2_off : 0);
   const unsigned char* tile_base = smem + (tile0 * 16 + l15) * stride + q4 * 16;
-  const bool active = h * 64 < a.Cout;  // wave-uniform: a 64-channel layer occupies the waves of half 0 only
+  const unsigned char* tile_base2 = tile2 + (tile0 * 16 + l15) * stride2 + q4 * 16;
   float4v acc[TPW][4];
-  // one copy of the unrolled main loop, run twice for a pair: two copies exceed the unroller's size budget, which
-  // then leaves the tile loop rolled with its fragment addresses computed at run time
-#pragma unroll 1
+  // same width: one copy of the unrolled main loop, run twice (two copies of it only cost instruction-cache misses);
+  // two widths: two straight-line stages
+#pragma unroll(CIN2 != CIN ? 2 : 1)
   for (int stage = 0; stage < (PAIR ? 2 : 1); ++stage) {
     const unsigned short* wsrc = (PAIR && stage == 1) ? a.w2 : a.w;
     const float* bsrc = (PAIR && stage == 1) ? a.bias2 : a.bias;
+    // wave-uniform: a 64-channel layer occupies the waves of half 0 only
+    const bool active = h * 64 < ((PAIR && stage == 0 && CIN2 != CIN) ? CIN2 : a.Cout);
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
@@ -121,7 +133,10 @@ __device__ __forceinline__ void flat_convs(const FlatConvArgs& a, unsigned char*
       for (int ws = 0; ws < 2; ++ws)
 #pragma unroll
         for (int i = 0; i < 8; ++i) bias[ws][i] = bsrc[(2 * h + ws) * 32 + q4 * 8 + i];
-      flatconv_mainloop<CIN, TPW>(acc, wsrc, tile_base, P, h, lane);
+      if (PAIR && stage == 1 && CIN2 != CIN)
+        flatconv_mainloop<CIN2, TPW>(acc, wsrc, tile_base2, P, h, lane);
+      else
+        flatconv_mainloop<CIN, TPW>(acc, wsrc, tile_base, P, h, lane);
     }
     FLAT_PHASE(3 + stage * 4);
     __syncthreads();  // every wave is done reading the tile: it is overwritten in place / reused as the output tile
@@ -155,7 +170,7 @@ __device__ __forceinline__ void flat_convs(const FlatConvArgs& a, unsigned char*
             }
             const short8 o = pixel ? pack_bf16x8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3])
                                    : (short8){0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<short8*>(smem + (f + P + 1) * stride + (2 * h + ws) * 64 + q4 * 16) = o;
+            *reinterpret_cast<short8*>(tile2 + (f + P + 1) * stride2 + (2 * h + ws) * 64 + q4 * 16) = o;
           }
         }
       }
@@ -186,7 +201,9 @@ __device__ __forceinline__ void flat_convs(const FlatConvArgs& a, unsigned char*
 
 // PAIR: a whole residual block (alphatriangle/nn/model.py:40-59) per launch, 128 channels throughout; the skip
 // connection stays in the registers that staged the block input.
-template <int CIN, int TPW, bool PAIR, bool PROBE = false>
+// FIRST (with PAIR and CIN2): the conv stem in one launch - board plane -> conv(1 -> CIN) while staging ->
+// conv(CIN -> CIN2) -> conv(CIN2 -> Cout); only the last layer's output goes to memory.
+template <int CIN, int TPW, bool PAIR, bool PROBE = false, bool FIRST = false, int CIN2 = CIN>
 __global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,7 +219,56 @@ __global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs 
   // runs, spare column, overhang) are zero-filled while the loads are under way.  A residual block keeps the chunks
   // in registers: they are its skip connection.
   uint4 xin[8];
-  {
+  if constexpr (FIRST) {
+    // board plane (with a zero border: taps need no bounds checks), first-layer weights and bias go to a side area of
+    // LDS; then every thread evaluates the single-channel 3x3 conv for its (flat position, 8-channel chunk) slots
+    // straight into the flat tile, zeros for the positions that are no pixel.  The second tile starts all zero.
+    float* aux = reinterpret_cast<float*>(smem + a.aux_off);
+    const int PW = W + 2, plane = (H + 2) * PW;
+    float* gplane = aux;
+    float* wl = aux + a.plane_w;  // [9][CIN]
+    float* bl = wl + 9 * CIN;     // [CIN]
+    for (int i = tid; i < plane; i += kFlatThreads) {
+      const int yy = i / PW - 1, xx = i - (yy + 1) * PW - 1;
+      gplane[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? a.grid[(size_t)b * a.HW + yy * W + xx] : 0.f;
+    }
+    for (int i = tid; i < 9 * CIN; i += kFlatThreads) wl[i] = a.w_first[i];
+    for (int i = tid; i < CIN; i += kFlatThreads) bl[i] = a.b_first[i];
+    constexpr int stride2 = CIN2 * 2 + 32;
+    for (int c = tid; c < a.rows * stride2 / 16; c += kFlatThreads)
+      reinterpret_cast<uint4*>(smem + a.tile2_off)[c] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    constexpr int CPR = CIN / 8;
+    for (int c = tid; c < a.rows * CPR; c += kFlatThreads) {
+      const int r = c / CPR, cc = c - r * CPR;
+      const int rr = r - (P + 1);
+      const int y = (rr * a.pmagic) >> 16, x = rr - y * P;
+      short8 o = (short8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (rr >= 0 && y < H && x < W) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bl[cc * 8 + j];
+        const float* gp = gplane + y * PW + x;  // top-left tap of this pixel in the padded plane
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const float gv = gp[(tap / 3) * PW + tap % 3];
+          const float4* wq = reinterpret_cast<const float4*>(wl + tap * CIN + cc * 8);
+          const float4 w0 = wq[0], w1 = wq[1];
+          v[0] += gv * w0.x; v[1] += gv * w0.y; v[2] += gv * w0.z; v[3] += gv * w0.w;
+          v[4] += gv * w1.x; v[5] += gv * w1.y; v[6] += gv * w1.z; v[7] += gv * w1.w;
+        }
+        if (a.act == kActReLU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], a.act);
+        }
+        o = pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+      }
+      *reinterpret_cast<short8*>(smem + r * stride + cc * 16) = o;
+    }
+  } else {
     const int l2 = a.log2_cpr, cmask = (1 << l2) - 1;
     const int total = a.HW << l2;
     const unsigned short* src = a.in + (size_t)b * a.HW * a.Cin;
@@ -233,9 +299,9 @@ __global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs 
   // channel half and tile quarter of this wave; the first `full_groups` quarters hold TPW tiles, the others TPW - 1
   const int h = wave & 1, tq = wave >> 1;
   if (tq < a.full_groups)  // wave-uniform
-    flat_convs<CIN, TPW, PAIR, PROBE>(a, smem, tq * TPW, h, lane);
+    flat_convs<CIN, TPW, PAIR, PROBE, CIN2>(a, smem, tq * TPW, h, lane);
   else
-    flat_convs<CIN, TPW - 1, PAIR, PROBE>(a, smem, a.full_groups + tq * (TPW - 1), h, lane);
+    flat_convs<CIN, TPW - 1, PAIR, PROBE, CIN2>(a, smem, a.full_groups + tq * (TPW - 1), h, lane);
 
   // ---- coalesced write-back: thread -> (pixel, 8-channel chunk), whole rows per wave ----
   const int n_ch = min(128, a.Cout);
@@ -245,7 +311,7 @@ __global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs 
   const size_t gbase = (size_t)b * a.HW * a.Cout;
   for (int c0 = tid; c0 < chunks; c0 += kFlatThreads * 8) {
     short8 rv[8];
-    if (PAIR) {  // the skip connection is the block input: same (pixel, chunk) mapping as the staging, still in registers
+    if (PAIR && !FIRST) {  // the skip connection is the block input: same (pixel, chunk) mapping as the staging, still in registers
 #pragma unroll
       for (int i = 0; i < 8; ++i) rv[i] = __builtin_bit_cast(short8, xin[i]);
     } else if (a.residual != nullptr) {
@@ -265,7 +331,7 @@ __global__ __launch_bounds__(kFlatThreads, 1) void flatconv_kernel(FlatConvArgs 
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = bf16_to_float((unsigned short)hv[j]);
-      if (PAIR || a.residual != nullptr) {
+      if ((PAIR && !FIRST) || a.residual != nullptr) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bf16_to_float((unsigned short)rv[i][j]);
       }
@@ -424,6 +490,52 @@ int atri_flatconv_pair(const void* in, const void* w1, const float* b1, const vo
     return hip_err(hipGetLastError());
   }
   return launch_flat_tpw<128, true>(a, tpw, lds, stream);
+}
+
+// Conv stem in one launch: board plane -> conv(1 -> C0) -> conv(C0 -> C1) -> conv(C1 -> C2), every layer followed by
+// the activation; only the last layer's output goes to memory.  (C0, C1, C2) = (32, 64, 128).
+// w_first [9][C0] / b_first [C0]: first layer (evaluated while staging); (w1, b1), (w2, b2): packed second and third layer.
+int atri_flatconv_stem(const float* grid, const float* w_first, const float* b_first, const void* w1, const float* b1,
+                       const void* w2, const float* b2, const float* post_add, void* out, int B, int H, int W, int C0, int C1,
+                       int C2, int act, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (C0 != 32 || C1 != 64 || C2 != 128 || !atri_flatconv_supported(H, W, C0, C1) || !atri_flatconv_supported(H, W, C1, C2)) return -10;
+  FlatConvArgs a{};
+  const int tpw = flat_tiles_per_wave(H, W);
+  if (flat_fill_geometry(a, H, W, C0, tpw) < 0) return -15;
+  a.w = (const unsigned short*)w1;
+  a.bias = b1;
+  a.w2 = (const unsigned short*)w2;
+  a.bias2 = b2;
+  a.post_add = post_add;
+  a.out = (unsigned short*)out;
+  a.B = B;
+  a.live = live_count_ptr();
+  a.Cout = C2;
+  a.act = act;
+  a.grid = grid;
+  a.w_first = w_first;
+  a.b_first = b_first;
+  const int tile1 = a.rows * (C0 * 2 + 32), tile2 = a.rows * (C1 * 2 + 32);
+  const int out_bytes = (a.rows - 2 * a.P - 2) * kFlatOutStride;
+  a.tile2_off = (tile1 + 15) & ~15;
+  int lds = a.tile2_off + tile2 > out_bytes ? a.tile2_off + tile2 : out_bytes;  // the output tile reuses both input tiles
+  a.aux_off = (lds + 15) & ~15;                                                  // board plane + first-layer weights behind them
+  a.plane_w = ((H + 2) * (W + 2) + 3) & ~3;
+  lds = a.aux_off + (a.plane_w + 10 * C0) * 4;
+  if (lds > 160 * 1024) return -15;
+#define ATRI_FLAT_STEM(T)                                                                                                          \
+  {                                                                                                                               \
+    static bool attr = false;                                                                                                     \
+    if (!attr) {                                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)flatconv_kernel<32, T, true, false, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr = true;                                                                                                                \
+    }                                                                                                                             \
+    hipLaunchKernelGGL((flatconv_kernel<32, T, true, false, true, 64>), dim3(B), dim3(kFlatThreads), lds, stream, a);             \
+  }
+  if (tpw == 3) ATRI_FLAT_STEM(3) else if (tpw == 4) ATRI_FLAT_STEM(4) else ATRI_FLAT_STEM(5)
+#undef ATRI_FLAT_STEM
+  return hip_err(hipGetLastError());
 }
 
 // Diagnostics: while `clock` (12 x int64 of device memory) is set, atri_flatconv_pair launches on 5-tile boards run

@@ -9,6 +9,7 @@ is the reference's (alphatriangle/nn/model.py:109-297).
 
 Layer -> kernel map (default config, B leaves, HW = 120 tokens):
   conv stem 1 -> 32 -> 64 -> 128         rowconv_kernel<32, FIRST, PAIR, 64>: one launch, intermediates in LDS halo tiles
+                                         (boards above 8x15: flatconv_kernel<32, TPW, PAIR, FIRST, 64>, flat tiles)
   conv stem layer 0 (Cin = 1), others    evaluated inside the staging of layer 1's rowconv_kernel (boards up to 8x15),
                                          else conv_first_kernel (VALU, memory bound)
   residual blocks (128 channels)         rowconv_kernel<PAIR>: both convolutions in one launch, intermediate in LDS
@@ -621,7 +622,22 @@ class InferenceEngine:
             and body[0][1].cout == 64 and body[1][1].cin == 64 and body[1][1].cout == 128 and body[1][1].taps == 9
             and body[0][1].act == self.act and body[1][1].act == self.act and body[1][1].ln_g is None and self.HW <= 128
         )
-        if fuse_stem:
+        flat_stem = (
+            not fuse_stem and self.use_rowconv and self.fuse_stem and len(body) >= 2 and body[0][0] == "plain"
+            and body[1][0] == "plain" and self.c0 == 32 and body[0][1].taps == 9 and body[1][1].taps == 9
+            and body[0][1].cin == 32 and body[0][1].cout == 64 and body[1][1].cin == 64 and body[1][1].cout == 128
+            and body[0][1].post_add is None and body[0][1].ln_g is None and body[1][1].ln_g is None
+            and body[0][1].act == self.act and body[1][1].act == self.act and self._flat_ok(32, 64) and self._flat_ok(64, 128)
+        )
+        if flat_stem:
+            # the same one-launch conv stem on a board above 8x15 (csrc/hip/flatconv_kernels.hip)
+            l1, l2 = body[0][1], body[1][1]
+            hb.call("atri_flatconv_stem", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.ptr(l1.w), hb.ptr(l1.bias),
+                    hb.ptr(l2.w), hb.ptr(l2.bias), hb.ptr(l2.post_add), hb.ptr(bufs[1]), hb.i32(B), hb.i32(self.H), hb.i32(self.W),
+                    hb.i32(self.c0), hb.i32(l1.cout), hb.i32(l2.cout), hb.i32(self.act))
+            cur = 1
+            body = body[2:]
+        elif fuse_stem:
             # whole conv stem (1 -> 32 -> 64 -> 128 channels) in one launch: only the last layer's output goes to memory
             l1, l2 = body[0][1], body[1][1]
             hb.call("atri_rowconv_stem", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.ptr(l1.w), hb.ptr(l1.bias),

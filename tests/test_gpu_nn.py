@@ -398,6 +398,56 @@ def test_flatconv_pair_matches_two_launches_and_torch(act, h, w):
     assert err <= 0.02 * scale + 0.03, f"max err {err} (scale {scale})"
 
 
+@pytest.mark.parametrize("act,h,w", [(1, 12, 21), (2, 12, 21), (1, 9, 16), (1, 16, 15)])
+def test_flatconv_stem_matches_per_layer_launches_and_torch(act, h, w):
+    """flatconv_kernel<FIRST, PAIR, 64> (board plane -> 32 -> 64 -> 128 channels in one launch) against conv_first +
+    two flat-tile launches and against the fp32 definition."""
+    from alphatriangle_amd.ops import hipbind as hb
+    from alphatriangle_amd.ops.inference import pack_gemm_weights
+
+    torch.manual_seed(31)
+    dev = _dev()
+    B, H, W = 6, h, w
+    HW = H * W
+    grid = torch.randint(-1, 2, (B, HW), device=dev).float()
+    w0 = torch.randn(32, 1, 3, 3, device=dev) * 0.4
+    b0 = torch.randn(32, device=dev) * 0.2
+    w1 = _bf16_round(torch.randn(64, 32, 3, 3, device=dev) * (1.0 / math.sqrt(32 * 9)))
+    w2 = _bf16_round(torch.randn(128, 64, 3, 3, device=dev) * (1.0 / math.sqrt(64 * 9)))
+    b1, b2 = torch.randn(64, device=dev) * 0.3, torch.randn(128, device=dev) * 0.3
+    post = torch.randn(HW, 128, device=dev)
+    fact = F.relu if act == 1 else F.gelu
+    x0 = _bf16_round(fact(F.conv2d(grid.view(B, 1, H, W), w0, b0, padding=1)))  # intermediates are bf16 in the kernels
+    x1 = _bf16_round(fact(F.conv2d(x0, w1, b1, padding=1)))
+    ref = fact(F.conv2d(x1, w2, b2, padding=1)).permute(0, 2, 3, 1).reshape(B, HW, 128) + post[None]
+    wf = w0.reshape(32, 9).t().contiguous()
+    p1, _ = pack_gemm_weights(w1.permute(2, 3, 1, 0).reshape(9, 32, 64), dev)
+    p2, _ = pack_gemm_weights(w2.permute(2, 3, 1, 0).reshape(9, 64, 128), dev)
+    b1p = torch.zeros(128, device=dev)
+    b1p[:64] = b1
+    fused = torch.zeros(B * HW, 128, dtype=torch.bfloat16, device=dev)
+    hb.call("atri_flatconv_stem", hb.ptr(grid), hb.ptr(wf), hb.ptr(b0), hb.ptr(p1), hb.ptr(b1p), hb.ptr(p2), hb.ptr(b2),
+            hb.ptr(post), hb.ptr(fused), hb.i32(B), hb.i32(H), hb.i32(W), hb.i32(32), hb.i32(64), hb.i32(128), hb.i32(act))
+    t0 = torch.zeros(B * HW, 32, dtype=torch.bfloat16, device=dev)
+    t1 = torch.zeros(B * HW, 64, dtype=torch.bfloat16, device=dev)
+    sep = torch.zeros_like(fused)
+    hb.call("atri_conv_first", hb.ptr(grid), hb.ptr(wf), hb.ptr(b0), hb.ptr(t0), hb.i32(B * HW), hb.i32(HW), hb.i32(H), hb.i32(W),
+            hb.i32(32), hb.i32(act))
+    hb.call("atri_flatconv", hb.ptr(t0), hb.ptr(p1), hb.ptr(b1p), hb.ptr(None), hb.ptr(None), hb.ptr(t1),
+            hb.i32(B), hb.i32(H), hb.i32(W), hb.i32(32), hb.i32(64), hb.i32(act))
+    hb.call("atri_flatconv", hb.ptr(t1), hb.ptr(p2), hb.ptr(b2), hb.ptr(None), hb.ptr(post), hb.ptr(sep),
+            hb.i32(B), hb.i32(H), hb.i32(W), hb.i32(64), hb.i32(128), hb.i32(act))
+    torch.cuda.synchronize()
+    if act == 1:
+        assert torch.equal(fused, sep)  # rounding to bf16 commutes with ReLU
+    else:
+        assert (fused.float() - sep.float()).abs().max().item() < 0.08
+    got = fused.float().view(B, HW, 128)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 0.02 * scale + 0.04, f"max err {err} (scale {scale})"
+
+
 def test_large_board_flat_and_tile_gemm_conv_paths_agree():
     """The 12x21 preset through flatconv_kernel (stem layers, fused residual blocks) and through the generic tile kernel."""
     from alphatriangle_amd.models.network import NeuralNetwork
