@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
         *reinterpret_cast<float4*>(op + 4) = make_float4(acc[t][1][0] + bias[4], acc[t][1][1] + bias[5], acc[t][1][2] + bias[6], acc[t][1][3] + bias[7]);
       }
     }
-    __syncthreads();
+    break;  // last stage: the barrier that publishes the output tile comes after the skip-connection loads below
   }
 
   // ---- coalesced write-back: thread -> (pixel, 4-channel chunk), whole pixel rows per 32 lanes ----
@@ -312,18 +312,26 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
   while ((1 << l2c) < cpp) ++l2c;
   const int chunks = a.HW << l2c;
   const size_t gbase = (size_t)b * a.HW * a.Cout;
-  for (int c0 = tid; c0 < chunks; c0 += 256 * 8) {
-    // skip-connection rows and positional-table values of all eight chunks are requested before the first is used: a
-    // table value read inside the chunk loop would wait for the previous chunk's store as well (one counter for both)
-    float4 rv[8], pv[8];
-    if (a.residual != nullptr) {
+  // The skip-connection rows of the whole sample (at most 16 chunks per thread: 128 pixels x 32 chunks) are requested
+  // now that the accumulators are dead, before the barrier: they arrive while the workgroup waits for its last wave.
+  float4 rall[16];
+  if (a.residual != nullptr) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + i * 256;
-        rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < chunks) rv[i] = *reinterpret_cast<const float4*>(a.residual + gbase + (size_t)(c >> l2c) * a.Cout + (c & (cpp - 1)) * 4);
-      }
+    for (int i = 0; i < 16; ++i) {
+      const int c = min(tid + i * 256, chunks - 1);
+      rall[i] = *reinterpret_cast<const float4*>(a.residual + gbase + (size_t)(c >> l2c) * a.Cout + (c & (cpp - 1)) * 4);
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int c0 = tid + half * 256 * 8;
+    if (c0 >= chunks) break;
+    // positional-table values of all eight chunks are requested before the first is used: a table value read inside
+    // the chunk loop would wait for the previous chunk's store as well (one counter for both)
+    float4 rv[8], pv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rv[i] = rall[half * 8 + i];
     if (a.post_add != nullptr) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
