@@ -23,7 +23,7 @@ from ...config.system_config import SystemConfig
 from ...config.train_config import TrainConfig
 from ...ops import hip_learner
 from ...stats.serializer import experiences_from_arrays
-from ...utils.types import Experience
+from ...utils.types import Experience, experience_to_columns
 from .trainer import TensorBatch
 
 logger = logging.getLogger(__name__)
@@ -120,20 +120,8 @@ class DeviceReplayBuffer:
     def add_batch(self, experiences: list[Experience]) -> None:
         if not experiences:
             return
-        n = len(experiences)
-        grid = np.stack([np.asarray(e[0]["grid"], dtype=np.float32).reshape(-1) for e in experiences])
-        other = np.stack([np.asarray(e[0]["other_features"], dtype=np.float32) for e in experiences])
-        policy = np.zeros((n, self.action_dim), dtype=np.float32)
-        for i, e in enumerate(experiences):
-            tgt = e[1]
-            if isinstance(tgt, np.ndarray):
-                policy[i, : min(self.action_dim, tgt.shape[0])] = tgt[: self.action_dim]
-            else:
-                for a, p in tgt.items():
-                    if 0 <= a < self.action_dim:
-                        policy[i, a] = p
-        rets = np.asarray([float(e[2]) for e in experiences], dtype=np.float32)
-        self.add_arrays(torch.from_numpy(grid), torch.from_numpy(other), torch.from_numpy(policy), torch.from_numpy(rets))
+        cols = experience_to_columns(experiences, self.action_dim)
+        self.add_arrays(*(torch.from_numpy(np.ascontiguousarray(c)) for c in cols))
 
     def add_arrays(self, grid: torch.Tensor, other: torch.Tensor, policy: torch.Tensor, rets: torch.Tensor, priority: float | None = None) -> None:
         n = int(grid.shape[0])

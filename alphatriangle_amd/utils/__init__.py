@@ -7,21 +7,25 @@ from .types import (
     ActionType,
     Experience,
     ExperienceBatch,
+    ExperienceColumns,
     PERBatchSample,
     PolicyTargetMapping,
     PolicyValueOutput,
     StateType,
+    experience_to_columns,
 )
 
 __all__ = [
     "ActionType",
     "Experience",
     "ExperienceBatch",
+    "ExperienceColumns",
     "PERBatchSample",
     "PolicyTargetMapping",
     "PolicyValueOutput",
     "StateType",
     "SumTree",
+    "experience_to_columns",
     "format_eta",
     "get_device",
     "is_point_in_polygon",

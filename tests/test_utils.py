@@ -65,3 +65,22 @@ def test_setup_logging(tmp_path):
     assert root.level == logging.DEBUG and any(isinstance(h, logging.StreamHandler) for h in root.handlers)
     setup_logging("INFO")
     assert len(logging.getLogger().handlers) == 1
+
+
+def test_experience_to_columns_densifies_sparse_and_dense_policy_targets():
+    import numpy as np
+
+    from alphatriangle_amd.utils import ExperienceColumns, experience_to_columns
+
+    batch = [
+        ({"grid": np.ones((1, 2, 3), np.float32), "other_features": np.arange(4, dtype=np.float32)}, {1: 0.25, 5: 0.75, 9: 1.0}, 2.5),
+        ({"grid": np.zeros((1, 2, 3), np.float32), "other_features": np.zeros(4, np.float32)},
+         np.array([0.5, 0.5, 0, 0, 0, 0, 0, 0], np.float32), -1.0),
+    ]
+    cols = experience_to_columns(batch, 6)
+    assert isinstance(cols, ExperienceColumns)
+    assert cols.grid.shape == (2, 6) and cols.other.shape == (2, 4) and cols.policy.shape == (2, 6)
+    assert cols.policy[0].tolist() == [0, 0.25, 0, 0, 0, 0.75]  # action 9 lies outside the action space and is dropped
+    assert cols.policy[1].tolist() == [0.5, 0.5, 0, 0, 0, 0]
+    assert cols.ret.tolist() == [2.5, -1.0] and cols.ret.dtype == np.float32
+    assert experience_to_columns([], 6).policy.shape == (0, 6)
