@@ -76,6 +76,8 @@ __device__ __forceinline__ void flatconv_mainloop(float4v (&acc)[TPW][4], const 
   }
 #pragma unroll
   for (int i = 0; i < kFlatAhead; ++i) av[i] = *reinterpret_cast<const short8*>(FLATCONV_ROW(i));
+  // unroll(full), not `#pragma unroll`: the latter left this loop half rolled (90 iterations x 2 trips for 180), and
+  // every fragment address was then recomputed from the loop counter by ~18 scalar instructions per four MFMAs
 #pragma clang loop unroll(full)
   for (int i = 0; i < TOTAL; ++i) {
     const int s = i / TPW, t = i % TPW, wc = s % 3;

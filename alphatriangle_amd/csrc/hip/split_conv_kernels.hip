@@ -91,6 +91,7 @@ __device__ __forceinline__ void split_mainloop(float4v (&acc)[8][2], const unsig
     xh[i] = *reinterpret_cast<const short8*>(base_hi + SPLIT_ROW(i / NR, R0 + i % NR));
     xl[i] = *reinterpret_cast<const short8*>(base_lo + SPLIT_ROW(i / NR, R0 + i % NR));
   }
+  // unroll(full), not `#pragma unroll`: the 128-channel instantiation (96 iterations) was left as two half-rolled trips
 #pragma clang loop unroll(full)
   for (int i = 0; i < GROUPS * NR; ++i) {
     const int g = i / NR, r = R0 + i % NR, wc = g & 1, wn = wc ^ 1;
