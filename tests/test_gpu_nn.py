@@ -155,11 +155,15 @@ def test_engine_forward_matches_pytorch_module(preset):
     lerr = (logits - ref_logits).abs().max().item()
     verr = (value - ref_value).abs().max().item()
     lscale = ref_logits.abs().max().item()
-    assert lerr < 0.05 * max(lscale, 1.0) + 0.03, f"logit err {lerr} (scale {lscale})"
-    assert verr < 0.15, f"value err {verr}"
-    # policy agreement where it matters: same top action for nearly every sample
-    agree = (logits.argmax(1) == ref_logits.argmax(1)).float().mean().item()
-    assert agree > 0.8
+    # what the bf16 kernels deliver on these nets: logit error 2 - 4e-3 at a logit scale of ~0.6, value error below 2e-3
+    assert lerr < 0.01 * max(lscale, 1.0) + 0.005, f"logit err {lerr} (scale {lscale})"
+    assert verr < 0.01, f"value err {verr}"
+    # same top action wherever the reference is not itself tied within the logit error (random-init logits are nearly flat)
+    same = logits.argmax(1) == ref_logits.argmax(1)
+    top2 = ref_logits.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 4 * lerr
+    assert clear.float().mean().item() > 0.3 and bool(same[clear].all())
+    assert same.float().mean().item() >= 0.9
 
 
 @pytest.mark.parametrize("hw,act_name", [(120, "relu"), (63, "gelu"), (128, "relu"), (16, "relu")])
