@@ -919,7 +919,8 @@ int atri_fc_rows_splitk(const void* rows, const float* other, int other_dim, con
   hipLaunchKernelGGL((fc_rows_splitk_kernel<MT, LN, 4>), dim3((B + MT * 16 - 1) / (MT * 16), SK), dim3(512), 0, stream, \
                      (const unsigned short*)rows, other, other_dim, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, \
                      other_pad, N, steps_per_split, live_count_ptr())
-  if (B >= 2048) {  // enough samples to fill the chip with 128-sample workgroups (half the weight reads of 64-sample ones)
+  // 128-sample workgroups read the weights half as often as 64-sample ones; taken when they still give every CU one
+  if ((long long)((B + 127) / 128) * SK >= 256) {
     if (g != nullptr) ATRI_FC_LAUNCH(8, true); else ATRI_FC_LAUNCH(8, false);
   } else {
     if (g != nullptr) ATRI_FC_LAUNCH(4, true); else ATRI_FC_LAUNCH(4, false);
