@@ -278,6 +278,9 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   const int HW = a.HW;
   const int nB = live_rows(a.live, a.B);
   if ((int)blockIdx.x >= nB) return;  // whole workgroup, before any barrier
+  // Two waves share a SIMD (w and w + 4); issue arbitration goes by priority, then age, so the second-dispatched half
+  // would lose every contested slot.  One static priority step for that half evens the pair out.
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
   const WRef none{nullptr, nullptr};
 
   // The workgroup is persistent: it walks samples blockIdx.x, blockIdx.x + gridDim.x, ...  The input rows of the next
