@@ -10,6 +10,27 @@ namespace {
 constexpr int kPitch = 288;  // bytes per 128-wide bf16 LDS row (256 + 32): 16-byte fragment reads of 16 rows x 4 column groups hit distinct banks
 }
 
+// How the FC launch's workgroups are dealt out for nB live rows.  The launch is sized for the full batch (row_blocks x
+// SK workgroups, steps_per_split K-steps each); with max_splits > SK the same workgroups cover only the row blocks that
+// hold leaves and split K further - up to max_splits ways - so that a thin batch still occupies every CU and each
+// workgroup walks a shorter K range.  Both the FC kernel and the tail kernel that sums the slabs derive the plan from
+// the device-side row count, so they agree without a host round trip.
+struct FcPlan {
+  int row_blocks, splits, steps;
+};
+__host__ __device__ inline FcPlan fc_plan(int nB, int rows_per_block, int full_row_blocks, int SK, int steps_per_split,
+                                          int total_steps, int max_splits) {
+  FcPlan p{full_row_blocks, SK, steps_per_split};
+  if (max_splits > SK && nB > 0) {
+    p.row_blocks = (nB + rows_per_block - 1) / rows_per_block;
+    int splits = full_row_blocks * SK / p.row_blocks;
+    if (splits > max_splits) splits = max_splits;
+    p.steps = ((total_steps + splits - 1) / splits + 3) & ~3;  // whole pixel rows (4 K-steps) per split
+    p.splits = (total_steps + p.steps - 1) / p.steps;          // no empty split at the end
+  }
+  return p;
+}
+
 // Shared FC fed directly by the body's [B][HW][128] fp32 rows, 64 samples x one K split per workgroup.  The final
 // LayerNorm - when there is one - is applied in fp32 to each 128-wide pixel row while it is staged (16 lanes per row;
 // LN = 1: normalisation only, the affine part folded into the weights by the host; LN = 2: with the affine part),
@@ -31,16 +52,21 @@ __global__ __launch_bounds__(512, 1) void fc_rows_split_kernel(const float* __re
                                                               const float* __restrict__ bt, float eps,
                                                               const unsigned short* __restrict__ Wp, long long lo_off,
                                                               float* __restrict__ slabs, int B, int HW, int other_pad, int N,
-                                                              int steps_per_split, const int* __restrict__ live) {
+                                                              int steps_per_split, const int* __restrict__ live,
+                                                              int max_splits) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[2][2][MT * 16 * kPitch];  // [buffer][plane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.x * (MT * 16);
   const int nB = live_rows(live, B);  // rows that hold leaves; B stays the slab pitch
-  if (b0 >= nB) return;               // whole workgroup, before any barrier
   const int feat_steps = HW * 4;
   const int total_steps = feat_steps + (other_pad >> 5);
-  const int s_begin = blockIdx.y * steps_per_split;
-  const int s_end = min(s_begin + steps_per_split, total_steps);
+  const FcPlan plan = fc_plan(nB, MT * 16, gridDim.x, gridDim.y, steps_per_split, total_steps, max_splits);
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;  // (row block, split) of this workgroup under the plan
+  const int split = wg / plan.row_blocks;
+  if (split >= plan.splits) return;   // whole workgroup, before any barrier
+  const int b0 = (wg - split * plan.row_blocks) * (MT * 16);
+  if (b0 >= nB) return;
+  const int s_begin = split * plan.steps;
+  const int s_end = min(s_begin + plan.steps, total_steps);
   if (s_begin >= s_end) return;
   const int n_rows = (s_end - s_begin + 3) >> 2;                                          // chunks of 4 K-steps in this split
   const int n_feat = s_begin < feat_steps ? (min(s_end, feat_steps) - s_begin) >> 2 : 0;  // of which pixel rows of the body
@@ -202,7 +228,7 @@ __global__ __launch_bounds__(512, 1) void fc_rows_split_kernel(const float* __re
     __syncthreads();  // chunk i + 1 is staged; every consumer is past its reads of this buffer
   }
   if (!wave_active) return;
-  float* slab = slabs + (size_t)blockIdx.y * B * 128;
+  float* slab = slabs + (size_t)split * B * 128;
   const int ch0 = wave * 32 + q4 * 8;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -233,6 +259,8 @@ struct SplitHeadsArgs {
   int B, SK, act, nbp, a_store, logit_stride, atoms, atoms_store, value_stride;
   float vmin, dz;
   const int* live;             // device row count (nullptr: B rows), see common.hpp; B stays the slab pitch
+  // the FC launch whose slabs these are (fc_plan): with fc_max_splits > SK the number of slabs follows the live count
+  int fc_rows_per_block, fc_row_blocks, fc_steps_per_split, fc_total_steps, fc_max_splits;
 };
 
 namespace {
@@ -297,7 +325,9 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
       const float4 c0 = bp[0], c1 = bp[1];
       v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
       v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-      for (int s = 0; s < a.SK; ++s) {
+      const int n_slabs = fc_plan(nB, a.fc_rows_per_block, a.fc_row_blocks, a.SK, a.fc_steps_per_split, a.fc_total_steps,
+                                  a.fc_max_splits).splits;
+      for (int s = 0; s < n_slabs; ++s) {
         const float4* sp = reinterpret_cast<const float4*>(a.slabs + ((size_t)s * a.B + b) * 128 + n0);
         const float4 p0 = sp[0], p1 = sp[1];
         v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
@@ -401,9 +431,11 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
 
 extern "C" {
 
-int atri_split_fc_rows(const float* rows, const float* other, int other_dim, const float* g, const float* bt, float eps,
-                       const void* Wp, long long lo_off, float* slabs, int B, int HW, int D, int other_pad, int N, int SK,
-                       int steps_per_split, hipStream_t stream) {
+// max_splits > SK: slabs must hold max_splits x B x 128 floats; the split count then follows the live row count (fc_plan)
+// and atri_split_heads_dyn has to be given the same numbers.
+int atri_split_fc_rows_dyn(const float* rows, const float* other, int other_dim, const float* g, const float* bt, float eps,
+                           const void* Wp, long long lo_off, float* slabs, int B, int HW, int D, int other_pad, int N, int SK,
+                           int steps_per_split, int max_splits, hipStream_t stream) {
   if (B <= 0) return 0;
   if (D != 128 || (other_pad & 31) != 0 || other_dim < 0 || other_dim > other_pad || N > 128 || (N & 31) != 0) return -10;
   if ((steps_per_split & 3) != 0 || steps_per_split <= 0) return -11;
@@ -413,7 +445,7 @@ int atri_split_fc_rows(const float* rows, const float* other, int other_dim, con
   const dim3 grid((B + 63) / 64, SK);
 #define ATRI_FC_LAUNCH(LN)                                                                                                \
   hipLaunchKernelGGL((fc_rows_split_kernel<4, LN, 4>), grid, dim3(512), 0, stream, rows, other, other_dim, g, bt, eps,    \
-                     (const unsigned short*)Wp, lo_off, slabs, B, HW, other_pad, N, steps_per_split, live_count_ptr())
+                     (const unsigned short*)Wp, lo_off, slabs, B, HW, other_pad, N, steps_per_split, live_count_ptr(), max_splits)
   if (g != nullptr) {
     ATRI_FC_LAUNCH(2);
   } else if (eps > 0.f) {
@@ -425,11 +457,28 @@ int atri_split_fc_rows(const float* rows, const float* other, int other_dim, con
   return hip_err(hipGetLastError());
 }
 
-int atri_split_heads(const float* slabs, int SK, const float* fc_bias, const void* wp1, long long lo_p1, const float* bp1,
-                     const void* wp2, long long lo_p2, const float* bp2, int nbp, int a_store, const void* wv1, long long lo_v1,
-                     const float* bv1, const void* wv2, long long lo_v2, const float* bv2, int atoms, int atoms_store,
-                     float* logits, int logit_stride, float* vlogits, int value_stride, float* values, float vmin, float dz,
-                     int B, int act, hipStream_t stream) {
+int atri_split_fc_rows(const float* rows, const float* other, int other_dim, const float* g, const float* bt, float eps,
+                       const void* Wp, long long lo_off, float* slabs, int B, int HW, int D, int other_pad, int N, int SK,
+                       int steps_per_split, hipStream_t stream) {
+  return atri_split_fc_rows_dyn(rows, other, other_dim, g, bt, eps, Wp, lo_off, slabs, B, HW, D, other_pad, N, SK,
+                                steps_per_split, 0, stream);
+}
+
+// The plan atri_split_fc_rows_dyn follows for n_live rows of a batch of B: out = {row blocks, splits, steps per split}.
+int atri_split_fc_plan(int n_live, int B, int SK, int steps_per_split, int total_steps, int max_splits, int* out) {
+  const FcPlan p = fc_plan(n_live < B ? n_live : B, 64, (B + 63) / 64, SK, steps_per_split, total_steps, max_splits);
+  out[0] = p.row_blocks;
+  out[1] = p.splits;
+  out[2] = p.steps;
+  return 0;
+}
+
+int atri_split_heads_dyn(const float* slabs, int SK, int fc_steps_per_split, int fc_total_steps, int fc_max_splits,
+                         const float* fc_bias, const void* wp1, long long lo_p1, const float* bp1,
+                         const void* wp2, long long lo_p2, const float* bp2, int nbp, int a_store, const void* wv1, long long lo_v1,
+                         const float* bv1, const void* wv2, long long lo_v2, const float* bv2, int atoms, int atoms_store,
+                         float* logits, int logit_stride, float* vlogits, int value_stride, float* values, float vmin, float dz,
+                         int B, int act, hipStream_t stream) {
   if (B <= 0) return 0;
   if (SK < 1 || nbp < 1 || a_store < 8 || (a_store & 7) || a_store > nbp * 128 || a_store > logit_stride) return -20;
   if (atoms < 1 || atoms > atoms_store || atoms_store > 128 || (atoms_store & 7) || atoms_store > value_stride) return -21;
@@ -448,8 +497,23 @@ int atri_split_heads(const float* slabs, int SK, const float* fc_bias, const voi
   a.atoms = atoms; a.atoms_store = atoms_store; a.value_stride = value_stride;
   a.vmin = vmin; a.dz = dz;
   a.live = live_count_ptr();
+  a.fc_rows_per_block = 64;
+  a.fc_row_blocks = (B + 63) / 64;
+  a.fc_steps_per_split = fc_steps_per_split;
+  a.fc_total_steps = fc_total_steps;
+  a.fc_max_splits = fc_max_splits;
   hipLaunchKernelGGL(heads_split_kernel, dim3((B + kHeadRowsS - 1) / kHeadRowsS), dim3(256), 0, stream, a);
   return hip_err(hipGetLastError());
+}
+
+int atri_split_heads(const float* slabs, int SK, const float* fc_bias, const void* wp1, long long lo_p1, const float* bp1,
+                     const void* wp2, long long lo_p2, const float* bp2, int nbp, int a_store, const void* wv1, long long lo_v1,
+                     const float* bv1, const void* wv2, long long lo_v2, const float* bv2, int atoms, int atoms_store,
+                     float* logits, int logit_stride, float* vlogits, int value_stride, float* values, float vmin, float dz,
+                     int B, int act, hipStream_t stream) {
+  return atri_split_heads_dyn(slabs, SK, 0, 0, 0, fc_bias, wp1, lo_p1, bp1, wp2, lo_p2, bp2, nbp, a_store, wv1, lo_v1, bv1, wv2,
+                              lo_v2, bv2, atoms, atoms_store, logits, logit_stride, vlogits, value_stride, values, vmin, dz, B,
+                              act, stream);
 }
 
 }  // extern "C"

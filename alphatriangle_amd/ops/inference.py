@@ -37,6 +37,7 @@ from __future__ import annotations
 
 import logging
 import math
+import os
 import threading
 from dataclasses import dataclass
 from typing import Any
@@ -437,6 +438,10 @@ class InferenceEngine:
         if self.fc_fused:
             self.fc_steps_per_split = ((total_steps + self.fc_sk - 1) // self.fc_sk + 3) // 4 * 4
             self.fc_sk = (total_steps + self.fc_steps_per_split - 1) // self.fc_steps_per_split
+        # fp32 engine: with a device-side live count below the batch, the FC's workgroups re-deal themselves over the row
+        # blocks that hold leaves and up to this many (shorter) K splits; the tail kernel derives the same plan
+        self.fc_max_splits = int(os.environ.get("ATRI_FC_MAX_SPLITS", "16")) if self.split else 0
+        self.fc_total_steps = total_steps
         # default-shaped tail (128-wide shared / policy / value hidden layers): one fused kernel
         pl, vl = self.policy_layers, self.value_layers
         self.heads_fused = (
@@ -464,7 +469,7 @@ class InferenceEngine:
         if self.split:
             self.bufs = [torch.empty(rows * 128, dtype=torch.float32, device=dev) for _ in range(3)]
             self.fc_in = self.vt = None
-            self.slabs = torch.empty(self.fc_sk, batch, 128, dtype=torch.float32, device=dev)
+            self.slabs = torch.empty(max(self.fc_sk, self.fc_max_splits), batch, 128, dtype=torch.float32, device=dev)
             self.dense = []
             self.logits = torch.zeros(batch, self.logit_stride, dtype=torch.float32, device=dev)
             self.vlogits = torch.zeros(batch, self.value_stride, dtype=torch.float32, device=dev)
@@ -560,13 +565,15 @@ class InferenceEngine:
                 cur = dst
             ln = self.final_ln
         g, bt, eps = ln if ln is not None else (None, None, 0.0)
-        hb.call("atri_split_fc_rows", hb.ptr(bufs[cur]), hb.ptr(other), hb.i32(self.other_dim), hb.ptr(g), hb.ptr(bt), hb.f32(eps),
+        hb.call("atri_split_fc_rows_dyn", hb.ptr(bufs[cur]), hb.ptr(other), hb.i32(self.other_dim), hb.ptr(g), hb.ptr(bt), hb.f32(eps),
                 hb.ptr(self.fc_w), hb.i64(self.fc_lo), hb.ptr(self.slabs), hb.i32(B), hb.i32(self.HW), hb.i32(self.feat_c),
-                hb.i32(self.other_pad), hb.i32(self.fc_n), hb.i32(self.fc_sk), hb.i32(self.fc_steps_per_split))
+                hb.i32(self.other_pad), hb.i32(self.fc_n), hb.i32(self.fc_sk), hb.i32(self.fc_steps_per_split),
+                hb.i32(self.fc_max_splits))
         p1, p2 = self.policy_layers
         v1, v2 = self.value_layers
         dz = (self.mc.VALUE_MAX - self.mc.VALUE_MIN) / (self.mc.NUM_VALUE_ATOMS - 1)
-        hb.call("atri_split_heads", hb.ptr(self.slabs), hb.i32(self.fc_sk), hb.ptr(self.fc_b), hb.ptr(p1.w), hb.i64(p1.lo_off),
+        hb.call("atri_split_heads_dyn", hb.ptr(self.slabs), hb.i32(self.fc_sk), hb.i32(self.fc_steps_per_split),
+                hb.i32(self.fc_total_steps), hb.i32(self.fc_max_splits), hb.ptr(self.fc_b), hb.ptr(p1.w), hb.i64(p1.lo_off),
                 hb.ptr(p1.bias), hb.ptr(p2.w), hb.i64(p2.lo_off), hb.ptr(p2.bias), hb.i32(p2.n_blocks), hb.i32(p2.cout),
                 hb.ptr(v1.w), hb.i64(v1.lo_off), hb.ptr(v1.bias), hb.ptr(v2.w), hb.i64(v2.lo_off), hb.ptr(v2.bias),
                 hb.i32(self.mc.NUM_VALUE_ATOMS), hb.i32(v2.cout), hb.ptr(self.logits), hb.i32(self.logit_stride),

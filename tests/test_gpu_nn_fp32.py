@@ -199,12 +199,35 @@ def test_search_picks_the_same_moves_under_bf16_fp32_engine_and_fp32_module():
     assert s16 >= 0.95 and kl16 < 0.05
 
 
+@pytest.mark.parametrize("batch,live,expect", [(1024, 1024, (16, 4, 124)), (1024, 900, (15, 4, 124)), (1024, 512, (8, 8, 64)),
+                                               (1024, 100, (2, 16, 32)), (1024, 1, (1, 16, 32)), (1024, 0, (16, 4, 124)),
+                                               (200, 64, (1, 7, 4))])
+def test_fp32_shared_fc_plan_follows_the_live_count(batch, live, expect):
+    """The (row blocks, K splits, steps per split) the FC's workgroups deal themselves for a live count: never more
+    workgroups than the launch holds, whole pixel rows per split, no empty split, the static plan for a full batch."""
+    import ctypes
+
+    from alphatriangle_amd.ops import hipbind as hb
+
+    total = 482 if batch == 1024 else 25
+    sk, steps = (4, 124) if batch == 1024 else (2, 16)
+    out = (ctypes.c_int * 3)()
+    getattr(hb.lib(), "atri_split_fc_plan")(hb.i32(live), hb.i32(batch), hb.i32(sk), hb.i32(steps), hb.i32(total), hb.i32(16), out)
+    blocks, splits, per = out[0], out[1], out[2]
+    assert (blocks, splits, per) == expect
+    assert blocks * splits <= (batch + 63) // 64 * sk and per % 4 == 0
+    assert (splits - 1) * per < total <= splits * per
+
+
 @pytest.mark.parametrize("ln_mode", ["affine", "plain", "none"])
-@pytest.mark.parametrize("batch,live", [(70, None), (200, 131)])
-def test_fp32_shared_fc_kernel_matches_fp64(ln_mode, batch, live):
+@pytest.mark.parametrize("batch,live,max_splits", [(70, None, 0), (200, 131, 0), (200, 131, 16), (200, 40, 16), (70, None, 16)])
+def test_fp32_shared_fc_kernel_matches_fp64(ln_mode, batch, live, max_splits):
     """The split-K shared-FC kernel on its own: body rows (+ LayerNorm in its three forms) and the "other" features
     against an fp64 evaluation, with K splits that end inside the body rows and inside the "other" chunk, sample counts
-    that are no multiple of the tile, and a device-side live count."""
+    that are no multiple of the tile, a device-side live count, and the split plan that follows that count (one of its
+    splits then holds nothing but the "other" chunk)."""
+    import ctypes
+
     from alphatriangle_amd.ops import hipbind as hb
     from alphatriangle_amd.ops.inference import pack_gemm_weights_split
 
@@ -221,14 +244,15 @@ def test_fp32_shared_fc_kernel_matches_fp64(ln_mode, batch, live):
     eps = 1e-5
     packed, _, lo = pack_gemm_weights_split(w.unsqueeze(0), dev)
     sk, steps_per_split = 2, 16  # 25 K-steps: split 0 = four pixel rows, split 1 = two pixel rows + the "other" chunk
-    slabs = torch.full((sk, batch, 128), float("nan"), device=dev)
+    slabs = torch.full((max(sk, max_splits), batch, 128), float("nan"), device=dev)
     live_t = None if live is None else torch.tensor([live], dtype=torch.int32, device=dev)
     set_live = getattr(hb.lib(), "atri_set_live_count")
     set_live(hb.ptr(live_t))
     try:
-        hb.call("atri_split_fc_rows", hb.ptr(rows), hb.ptr(other), hb.i32(other_dim), hb.ptr(g if ln_mode == "affine" else None),
+        hb.call("atri_split_fc_rows_dyn", hb.ptr(rows), hb.ptr(other), hb.i32(other_dim), hb.ptr(g if ln_mode == "affine" else None),
                 hb.ptr(bt if ln_mode == "affine" else None), hb.f32(0.0 if ln_mode == "none" else eps), hb.ptr(packed), hb.i64(lo),
-                hb.ptr(slabs), hb.i32(batch), hb.i32(HW), hb.i32(128), hb.i32(other_pad), hb.i32(N), hb.i32(sk), hb.i32(steps_per_split))
+                hb.ptr(slabs), hb.i32(batch), hb.i32(HW), hb.i32(128), hb.i32(other_pad), hb.i32(N), hb.i32(sk), hb.i32(steps_per_split),
+                hb.i32(max_splits))
     finally:
         set_live(hb.VP(0))
     torch.cuda.synchronize()
@@ -240,8 +264,13 @@ def test_fp32_shared_fc_kernel_matches_fp64(ln_mode, batch, live):
     feats = torch.cat([x.reshape(batch, -1), other.double(), torch.zeros(batch, other_pad - other_dim, dtype=torch.float64, device=dev)], dim=1)
     ref = feats @ w.double().to(dev)
     n = batch if live is None else live
-    out = slabs[:, :n].double().sum(0)
+    plan = (ctypes.c_int * 3)()
+    getattr(hb.lib(), "atri_split_fc_plan")(hb.i32(n), hb.i32(batch), hb.i32(sk), hb.i32(steps_per_split), hb.i32(kp // 32), hb.i32(max_splits), plan)
+    used = plan[1]  # slabs the plan fills: sk with the static plan, more when the live rows leave workgroups free
+    assert used == (7 if max_splits and n == 40 else sk)
+    out = slabs[:used, :n].double().sum(0)
     scale = float(ref[:n].abs().max())
     assert float((out - ref[:n]).abs().max()) < 2e-5 * scale
-    if live is not None:  # rows past the live count are not written
+    assert torch.isnan(slabs[used:]).all()  # neither slabs past the plan's splits
+    if live is not None:  # nor rows past the live count are written
         assert torch.isnan(slabs[:, n:]).all()
