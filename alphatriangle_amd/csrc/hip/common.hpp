@@ -114,4 +114,26 @@ __device__ __forceinline__ int live_rows(const int* live, int capacity) {
   return n < capacity ? n : capacity;
 }
 
+
+// How a shared-FC launch's workgroups are dealt out for nB live rows.  The launch is sized for the full batch
+// (full_row_blocks x SK workgroups, steps_per_split K-steps each); with max_splits > SK the same workgroups cover only
+// the row blocks that hold leaves and split K further - up to max_splits ways - so that a thin batch still occupies every
+// CU and each workgroup walks a shorter K range.  Both the FC kernel and the tail kernel that sums the slabs derive the
+// plan from the device-side row count, so they agree without a host round trip.
+struct FcPlan {
+  int row_blocks, splits, steps;
+};
+__host__ __device__ inline FcPlan fc_plan(int nB, int rows_per_block, int full_row_blocks, int SK, int steps_per_split,
+                                          int total_steps, int max_splits) {
+  FcPlan p{full_row_blocks, SK, steps_per_split};
+  if (max_splits > SK && nB > 0) {
+    p.row_blocks = (nB + rows_per_block - 1) / rows_per_block;
+    int splits = full_row_blocks * SK / p.row_blocks;
+    if (splits > max_splits) splits = max_splits;
+    p.steps = ((total_steps + splits - 1) / splits + 3) & ~3;  // whole pixel rows (4 K-steps) per split
+    p.splits = (total_steps + p.steps - 1) / p.steps;          // no empty split at the end
+  }
+  return p;
+}
+
 }  // namespace atrihip

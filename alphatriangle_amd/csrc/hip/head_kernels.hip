@@ -28,6 +28,8 @@ struct HeadsArgs {
   int B, SK, act, nbp, a_store, logit_stride, atoms, atoms_store, value_stride;
   float vmin, dz;
   const int* live;             // device row count (nullptr: B rows), see common.hpp; B stays the slab pitch
+  // the FC launch whose slabs these are (fc_plan): with fc_max_splits > SK the number of slabs follows the live count
+  int fc_rows_per_block, fc_row_blocks, fc_steps_per_split, fc_total_steps, fc_max_splits;
 };
 
 namespace {
@@ -98,7 +100,9 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadsArgs a) {
       const float4 c0 = bp[0], c1 = bp[1];
       v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
       v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-      for (int s = 0; s < a.SK; ++s) {
+      const int n_slabs = fc_plan(nB, a.fc_rows_per_block, a.fc_row_blocks, a.SK, a.fc_steps_per_split, a.fc_total_steps,
+                                  a.fc_max_splits).splits;
+      for (int s = 0; s < n_slabs; ++s) {
         const float4* sp = reinterpret_cast<const float4*>(a.slabs + ((size_t)s * a.B + b) * 128 + n0);
         const float4 p0 = sp[0], p1 = sp[1];
         v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
@@ -200,11 +204,15 @@ extern "C" {
 
 // Tail of the network for B samples.  Every hidden width is 128; `a_store` / `atoms_store` are the stored (multiple
 // of 8) widths of the two output layers, `nbp` the number of 128-channel weight blocks of the policy output layer.
-int atri_heads(const float* slabs, int SK, const float* fc_bias, const void* wp1, const float* bp1, const void* wp2,
-               const float* bp2, int nbp, int a_store, const void* wv1, const float* bv1, const void* wv2,
-               const float* bv2, int atoms, int atoms_store, float* logits, int logit_stride, float* vlogits,
-               int value_stride, float* values, float vmin, float dz, int B, int act, hipStream_t stream) {
+// fc_*: the atri_fc_rows_splitk_dyn launch that filled the slabs (samples per workgroup, steps per split, total
+// K-steps, max_splits); fc_max_splits <= SK: exactly SK slabs.
+int atri_heads_dyn(const float* slabs, int SK, int fc_rows_per_block, int fc_steps_per_split, int fc_total_steps,
+                   int fc_max_splits, const float* fc_bias, const void* wp1, const float* bp1, const void* wp2,
+                   const float* bp2, int nbp, int a_store, const void* wv1, const float* bv1, const void* wv2,
+                   const float* bv2, int atoms, int atoms_store, float* logits, int logit_stride, float* vlogits,
+                   int value_stride, float* values, float vmin, float dz, int B, int act, hipStream_t stream) {
   if (B <= 0) return 0;
+  if (fc_max_splits > SK && (fc_rows_per_block <= 0 || fc_steps_per_split <= 0 || fc_total_steps <= 0)) return -23;
   if (SK < 1 || nbp < 1 || a_store < 8 || (a_store & 7) || a_store > nbp * 128 || a_store > logit_stride) return -20;
   if (atoms < 1 || atoms > atoms_store || atoms_store > 128 || (atoms_store & 7) || atoms_store > value_stride) return -21;
   if (logit_stride & 3) return -22;  // float4 stores
@@ -234,8 +242,21 @@ int atri_heads(const float* slabs, int SK, const float* fc_bias, const void* wp1
   a.value_stride = value_stride;
   a.vmin = vmin;
   a.dz = dz;
+  a.fc_rows_per_block = fc_rows_per_block > 0 ? fc_rows_per_block : 64;
+  a.fc_row_blocks = (B + a.fc_rows_per_block - 1) / a.fc_rows_per_block;
+  a.fc_steps_per_split = fc_steps_per_split;
+  a.fc_total_steps = fc_total_steps;
+  a.fc_max_splits = fc_max_splits;
   hipLaunchKernelGGL(heads_kernel, dim3((B + kHeadRows - 1) / kHeadRows), dim3(256), 0, stream, a);
   return hip_err(hipGetLastError());
+}
+
+int atri_heads(const float* slabs, int SK, const float* fc_bias, const void* wp1, const float* bp1, const void* wp2,
+               const float* bp2, int nbp, int a_store, const void* wv1, const float* bv1, const void* wv2,
+               const float* bv2, int atoms, int atoms_store, float* logits, int logit_stride, float* vlogits,
+               int value_stride, float* values, float vmin, float dz, int B, int act, hipStream_t stream) {
+  return atri_heads_dyn(slabs, SK, 0, 0, 0, 0, fc_bias, wp1, bp1, wp2, bp2, nbp, a_store, wv1, bv1, wv2, bv2, atoms,
+                        atoms_store, logits, logit_stride, vlogits, value_stride, values, vmin, dz, B, act, stream);
 }
 
 }  // extern "C"

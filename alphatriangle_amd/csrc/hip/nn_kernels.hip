@@ -515,18 +515,23 @@ __global__ __launch_bounds__(512, 1) void fc_rows_splitk_kernel(const unsigned s
                                                                 const float* __restrict__ g, const float* __restrict__ bt,
                                                                 float eps, const unsigned short* __restrict__ Wp,
                                                                 float* __restrict__ slabs, int B, int HW, int other_pad,
-                                                                int N, int steps_per_split, const int* __restrict__ live) {
+                                                                int N, int steps_per_split, const int* __restrict__ live,
+                                                                int max_splits) {
   constexpr int kPitch = 288;  // bytes per tile row: 16-byte fragment reads of 16 rows x 4 column groups hit distinct banks
   constexpr int CH = MT;       // 16-byte chunks per producer thread and pixel row
   __shared__ __attribute__((aligned(16))) unsigned char xs[2][MT * 16 * kPitch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.x * (MT * 16);
   const int nB = live_rows(live, B);  // rows that hold leaves; B stays the slab pitch
-  if (b0 >= nB) return;               // whole workgroup, before any barrier
   const int feat_steps = HW * 4;
   const int total_steps = feat_steps + (other_pad >> 5);
-  const int s_begin = blockIdx.y * steps_per_split;
-  const int s_end = min(s_begin + steps_per_split, total_steps);
+  const FcPlan plan = fc_plan(nB, MT * 16, gridDim.x, gridDim.y, steps_per_split, total_steps, max_splits);
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;  // (row block, split) of this workgroup under the plan
+  const int split = wg / plan.row_blocks;
+  if (split >= plan.splits) return;   // whole workgroup, before any barrier
+  const int b0 = (wg - split * plan.row_blocks) * (MT * 16);
+  if (b0 >= nB) return;
+  const int s_begin = split * plan.steps;
+  const int s_end = min(s_begin + plan.steps, total_steps);
   if (s_begin >= s_end) return;
   const int n_rows = (s_end - s_begin + 3) >> 2;                                          // chunks of 4 K-steps in this split
   const int n_feat = s_begin < feat_steps ? (min(s_end, feat_steps) - s_begin) >> 2 : 0;  // of which pixel rows of the body
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(512, 1) void fc_rows_splitk_kernel(const unsigned s
     __syncthreads();  // chunk i + 1 is staged; every consumer is past its reads of this buffer
   }
   if (!wave_active) return;
-  float* slab = slabs + (size_t)blockIdx.y * B * 128;
+  float* slab = slabs + (size_t)split * B * 128;
   const int ch0 = wave * 32 + q4 * 8;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -908,9 +913,15 @@ int atri_fc_splitk(const void* X, const void* Wp, float* slabs, int B, int Kp, i
 
 // Fused flatten (+ final LayerNorm) + shared FC for bodies with 128 channels per pixel.  SK splits of
 // steps_per_split K-steps each (a multiple of 4); slabs is [SK][B][128] f32.
-int atri_fc_rows_splitk(const void* rows, const float* other, int other_dim, const float* g, const float* bt, float eps,
-                        const void* Wp, float* slabs, int B, int HW, int D, int other_pad, int N, int SK, int steps_per_split,
-                        hipStream_t stream) {
+// Samples per workgroup of atri_fc_rows_splitk: 128-sample workgroups read the weights half as often as 64-sample
+// ones; taken when they still give every CU one.
+int atri_fc_rows_splitk_block_rows(int B, int SK) { return (long long)((B + 127) / 128) * SK >= 256 ? 128 : 64; }
+
+// max_splits > SK: slabs must hold max_splits x B x 128 floats; the split count then follows the live row count (fc_plan)
+// and atri_heads_dyn has to be given the same numbers.
+int atri_fc_rows_splitk_dyn(const void* rows, const float* other, int other_dim, const float* g, const float* bt, float eps,
+                            const void* Wp, float* slabs, int B, int HW, int D, int other_pad, int N, int SK,
+                            int steps_per_split, int max_splits, hipStream_t stream) {
   if (B <= 0) return 0;
   if (D != 128 || (other_pad & 31) != 0 || other_dim < 0 || other_dim > other_pad || N > 128 || (N & 31) != 0) return -10;
   if ((steps_per_split & 3) != 0 || steps_per_split <= 0) return -11;
@@ -918,15 +929,21 @@ int atri_fc_rows_splitk(const void* rows, const float* other, int other_dim, con
 #define ATRI_FC_LAUNCH(MT, LN)                                                                                      \
   hipLaunchKernelGGL((fc_rows_splitk_kernel<MT, LN, 4>), dim3((B + MT * 16 - 1) / (MT * 16), SK), dim3(512), 0, stream, \
                      (const unsigned short*)rows, other, other_dim, g, bt, eps, (const unsigned short*)Wp, slabs, B, HW, \
-                     other_pad, N, steps_per_split, live_count_ptr())
-  // 128-sample workgroups read the weights half as often as 64-sample ones; taken when they still give every CU one
-  if ((long long)((B + 127) / 128) * SK >= 256) {
+                     other_pad, N, steps_per_split, live_count_ptr(), max_splits)
+  if (atri_fc_rows_splitk_block_rows(B, SK) == 128) {
     if (g != nullptr) ATRI_FC_LAUNCH(8, true); else ATRI_FC_LAUNCH(8, false);
   } else {
     if (g != nullptr) ATRI_FC_LAUNCH(4, true); else ATRI_FC_LAUNCH(4, false);
   }
 #undef ATRI_FC_LAUNCH
   return hip_err(hipGetLastError());
+}
+
+int atri_fc_rows_splitk(const void* rows, const float* other, int other_dim, const float* g, const float* bt, float eps,
+                        const void* Wp, float* slabs, int B, int HW, int D, int other_pad, int N, int SK, int steps_per_split,
+                        hipStream_t stream) {
+  return atri_fc_rows_splitk_dyn(rows, other, other_dim, g, bt, eps, Wp, slabs, B, HW, D, other_pad, N, SK, steps_per_split,
+                                 0, stream);
 }
 
 int atri_fc_finish(const float* slabs, const float* bias, void* out, int B, int N, int SK, int act,

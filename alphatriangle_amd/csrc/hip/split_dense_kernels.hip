@@ -10,27 +10,6 @@ namespace {
 constexpr int kPitch = 288;  // bytes per 128-wide bf16 LDS row (256 + 32): 16-byte fragment reads of 16 rows x 4 column groups hit distinct banks
 }
 
-// How the FC launch's workgroups are dealt out for nB live rows.  The launch is sized for the full batch (row_blocks x
-// SK workgroups, steps_per_split K-steps each); with max_splits > SK the same workgroups cover only the row blocks that
-// hold leaves and split K further - up to max_splits ways - so that a thin batch still occupies every CU and each
-// workgroup walks a shorter K range.  Both the FC kernel and the tail kernel that sums the slabs derive the plan from
-// the device-side row count, so they agree without a host round trip.
-struct FcPlan {
-  int row_blocks, splits, steps;
-};
-__host__ __device__ inline FcPlan fc_plan(int nB, int rows_per_block, int full_row_blocks, int SK, int steps_per_split,
-                                          int total_steps, int max_splits) {
-  FcPlan p{full_row_blocks, SK, steps_per_split};
-  if (max_splits > SK && nB > 0) {
-    p.row_blocks = (nB + rows_per_block - 1) / rows_per_block;
-    int splits = full_row_blocks * SK / p.row_blocks;
-    if (splits > max_splits) splits = max_splits;
-    p.steps = ((total_steps + splits - 1) / splits + 3) & ~3;  // whole pixel rows (4 K-steps) per split
-    p.splits = (total_steps + p.steps - 1) / p.steps;          // no empty split at the end
-  }
-  return p;
-}
-
 // Shared FC fed directly by the body's [B][HW][128] fp32 rows, 64 samples x one K split per workgroup.  The final
 // LayerNorm - when there is one - is applied in fp32 to each 128-wide pixel row while it is staged (16 lanes per row;
 // LN = 1: normalisation only, the affine part folded into the weights by the host; LN = 2: with the affine part),
@@ -464,7 +443,8 @@ int atri_split_fc_rows(const float* rows, const float* other, int other_dim, con
                                 steps_per_split, 0, stream);
 }
 
-// The plan atri_split_fc_rows_dyn follows for n_live rows of a batch of B: out = {row blocks, splits, steps per split}.
+// The plan atri_split_fc_rows_dyn (64 rows per workgroup) follows for n_live rows of a batch of B:
+// out = {row blocks, splits, steps per split}.
 int atri_split_fc_plan(int n_live, int B, int SK, int steps_per_split, int total_steps, int max_splits, int* out) {
   const FcPlan p = fc_plan(n_live < B ? n_live : B, 64, (B + 63) / 64, SK, steps_per_split, total_steps, max_splits);
   out[0] = p.row_blocks;

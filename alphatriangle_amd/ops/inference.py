@@ -438,9 +438,10 @@ class InferenceEngine:
         if self.fc_fused:
             self.fc_steps_per_split = ((total_steps + self.fc_sk - 1) // self.fc_sk + 3) // 4 * 4
             self.fc_sk = (total_steps + self.fc_steps_per_split - 1) // self.fc_steps_per_split
-        # fp32 engine: with a device-side live count below the batch, the FC's workgroups re-deal themselves over the row
-        # blocks that hold leaves and up to this many (shorter) K splits; the tail kernel derives the same plan
-        self.fc_max_splits = int(os.environ.get("ATRI_FC_MAX_SPLITS", "16")) if self.split else 0
+        # with a device-side live count below the batch, the fused FC's workgroups re-deal themselves over the row blocks
+        # that hold leaves and up to this many (shorter) K splits; the fused tail kernel derives the same plan.  On by
+        # default in the fp32 engine only: the bf16 FC is half as long to begin with and measured no gain from it.
+        self.fc_max_splits = int(os.environ.get("ATRI_FC_MAX_SPLITS", "16" if self.split else "0")) if self.fc_fused else 0
         self.fc_total_steps = total_steps
         # default-shaped tail (128-wide shared / policy / value hidden layers): one fused kernel
         pl, vl = self.policy_layers, self.value_layers
@@ -479,7 +480,7 @@ class InferenceEngine:
         self.bufs = [torch.empty(rows * maxc, dtype=torch.bfloat16, device=dev) for _ in range(5)]
         self.fc_in = None if self.fc_fused else torch.zeros(batch, self.fc_kp, dtype=torch.bfloat16, device=dev)
         self.vt = torch.zeros(batch * 4 * 32 * 256, dtype=torch.bfloat16, device=dev) if self.rows_attn else None
-        self.slabs = torch.empty(self.fc_sk, batch, 128, dtype=torch.float32, device=dev)
+        self.slabs = torch.empty(max(self.fc_sk, self.fc_max_splits), batch, 128, dtype=torch.float32, device=dev)
         dense_w = max([self.fc_n] + [l.cout for l in self.shared_rest + self.policy_layers + self.value_layers])
         self.dense = [torch.empty(batch * dense_w, dtype=torch.bfloat16, device=dev) for _ in range(3)]
         self.logits = torch.zeros(batch, self.logit_stride, dtype=torch.float32, device=dev)
@@ -758,11 +759,13 @@ class InferenceEngine:
             ln = self.final_ln
         else:
             ln = None
+        fused_tail = self.heads_fused and self.use_fused_heads
+        fc_splits = self.fc_max_splits if self.fc_fused and fused_tail else 0  # only the fused tail knows the plan
         if self.fc_fused:
             g, bt, eps = ln if ln is not None else (None, None, 0.0)
-            hb.call("atri_fc_rows_splitk", hb.ptr(bufs[cur]), hb.ptr(other), hb.i32(self.other_dim), hb.ptr(g), hb.ptr(bt), hb.f32(eps),
+            hb.call("atri_fc_rows_splitk_dyn", hb.ptr(bufs[cur]), hb.ptr(other), hb.i32(self.other_dim), hb.ptr(g), hb.ptr(bt), hb.f32(eps),
                     hb.ptr(self.fc_w), hb.ptr(self.slabs), hb.i32(B), hb.i32(self.HW), hb.i32(self.feat_c), hb.i32(self.other_pad),
-                    hb.i32(self.fc_n), hb.i32(self.fc_sk), hb.i32(self.fc_steps_per_split))
+                    hb.i32(self.fc_n), hb.i32(self.fc_sk), hb.i32(self.fc_steps_per_split), hb.i32(fc_splits))
         else:
             g, bt, eps = ln if ln is not None else (None, None, 0.0)
             hb.call("atri_rows_to_fc", hb.ptr(bufs[cur]), hb.ptr(g), hb.ptr(bt), hb.ptr(self.fc_in), hb.i32(rows),
@@ -771,12 +774,15 @@ class InferenceEngine:
                     hb.i32(self.other_pad), hb.i32(self.fc_kp), hb.i32(self.HW * self.feat_c))
             hb.call("atri_fc_splitk", hb.ptr(self.fc_in), hb.ptr(self.fc_w), hb.ptr(self.slabs), hb.i32(B), hb.i32(self.fc_kp),
                     hb.i32(self.fc_n), hb.i32(self.fc_sk))
-        if self.heads_fused and self.use_fused_heads:
+        if fused_tail:
             # split-K reduction, both heads and the C51 expectation in one launch (csrc/hip/head_kernels.hip)
             p1, p2 = self.policy_layers
             v1, v2 = self.value_layers
             dz = (self.mc.VALUE_MAX - self.mc.VALUE_MIN) / (self.mc.NUM_VALUE_ATOMS - 1)
-            hb.call("atri_heads", hb.ptr(self.slabs), hb.i32(self.fc_sk), hb.ptr(self.fc_b), hb.ptr(p1.w), hb.ptr(p1.bias),
+            block_rows = getattr(hb.lib(), "atri_fc_rows_splitk_block_rows")(hb.i32(B), hb.i32(self.fc_sk)) if fc_splits else 0
+            hb.call("atri_heads_dyn", hb.ptr(self.slabs), hb.i32(self.fc_sk), hb.i32(block_rows),
+                    hb.i32(self.fc_steps_per_split if fc_splits else 0), hb.i32(self.fc_total_steps), hb.i32(fc_splits),
+                    hb.ptr(self.fc_b), hb.ptr(p1.w), hb.ptr(p1.bias),
                     hb.ptr(p2.w), hb.ptr(p2.bias), hb.i32(p2.n_blocks), hb.i32(p2.cout), hb.ptr(v1.w), hb.ptr(v1.bias),
                     hb.ptr(v2.w), hb.ptr(v2.bias), hb.i32(self.mc.NUM_VALUE_ATOMS), hb.i32(v2.cout), hb.ptr(self.logits),
                     hb.i32(self.logit_stride), hb.ptr(self.vlogits), hb.i32(self.value_stride), hb.ptr(self.values),

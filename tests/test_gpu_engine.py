@@ -189,12 +189,13 @@ def test_per_game_step_metrics_and_slot_census():
     assert sum(c.values()) == actor.G * actor.waves_per_move and c["expand"] > 0
 
 
-@pytest.mark.parametrize("dtype,fc_splits", [("fp32", 0), ("fp32", 16), ("bf16", 0)])
+@pytest.mark.parametrize("dtype,fc_splits", [("fp32", 0), ("fp32", 16), ("bf16", 0), ("bf16", 32)])
 def test_compacted_leaf_batch_plays_the_same_games(dtype, fc_splits, monkeypatch):
     """COMPACT_LEAF_BATCH: the engine kernels skip the rows beyond the device-side live count.  Same seeds with and
     without it must give the same moves, rewards and replay contents - also once terminal leaves thin the batch out.
-    With the fp32 shared FC allowed to split K by the live count (fc_splits > 0) the partial sums are added in another
-    order in thin waves: moves, rewards and search policies still have to match, the bootstrapped returns to 1e-4."""
+    With the shared FC allowed to split K by the live count (fc_splits > 0) the partial sums are added in another
+    order in thin waves: moves, rewards and search policies still have to match, the bootstrapped returns to 1e-4
+    (fp32 engine) / 0.05 (bf16 engine, where a last-bit change before the bf16 rounding can move a value by 2^-8)."""
     monkeypatch.setenv("ATRI_FC_MAX_SPLITS", str(fc_splits))
     from alphatriangle_amd.models.network import NeuralNetwork
     from alphatriangle_amd.rl.core.device_buffer import DeviceReplayBuffer
@@ -233,7 +234,7 @@ def test_compacted_leaf_batch_plays_the_same_games(dtype, fc_splits, monkeypatch
 
     if fc_splits:
         assert torch.equal(canonical(pa, va * 0)[0], canonical(pb, vb * 0)[0])
-        assert torch.allclose(va.sort().values, vb.sort().values, atol=1e-4, rtol=0)
+        assert torch.allclose(va.sort().values, vb.sort().values, atol=1e-4 if dtype == "fp32" else 0.05, rtol=0)
         return
     (pa, va), (pb, vb) = canonical(pa, va), canonical(pb, vb)
     assert torch.equal(pa, pb) and torch.equal(va, vb)

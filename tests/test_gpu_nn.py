@@ -504,6 +504,39 @@ def test_live_count_rows_match_the_full_batch(preset):
     assert torch.isfinite(lz).all() and torch.isfinite(vz).all()  # nothing ran, nothing was corrupted
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", 0.02), ("fp32", 1e-4)])
+def test_live_count_fc_plan_matches_the_static_split(dtype, tol, monkeypatch):
+    """A thin batch re-deals the shared FC's workgroups over fewer row blocks and more K splits (600 rows launched, 70
+    live: 2 row blocks x 16 / 31 splits instead of 10 x 4 / 8); the tail kernel has to sum exactly those slabs.  Against
+    the static split the outputs may differ by the summation order only."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    monkeypatch.setenv("ATRI_FC_MAX_SPLITS", "16" if dtype == "fp32" else "32")  # the bf16 engine's default is the static split
+    torch.manual_seed(31)
+    dev = _dev()
+    env, mc = EnvConfig(), ModelConfig()
+    eng = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev, inference_dtype=dtype).engine
+    assert eng is not None and eng.fc_fused and eng.fc_max_splits > eng.fc_sk
+    B, n = 600, 70
+    grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    live = torch.tensor([n], dtype=torch.int32, device=dev)
+    eng.reserve(B)
+    eng.slabs.fill_(float("nan"))  # a slab the plan does not fill but the tail sums would poison the outputs
+    ld, vd = (t[:n].clone() for t in eng.forward(grid, other, live=live))
+    dynamic = eng.fc_max_splits
+    eng.fc_max_splits = 0
+    try:
+        ls, vs = (t[:n].clone() for t in eng.forward(grid, other, live=live))
+    finally:
+        eng.fc_max_splits = dynamic
+    torch.cuda.synchronize()
+    assert torch.isfinite(ld).all() and torch.isfinite(vd).all()
+    assert (ld - ls).abs().max().item() < tol and (vd - vs).abs().max().item() < tol
+    lf, vf = (t[:n].clone() for t in eng.forward(grid, other))  # full batch: the plan is the static one
+    assert torch.equal(lf, ls) and torch.equal(vf, vs)
+
+
 def test_rowconv_and_tile_gemm_paths_agree():
     from alphatriangle_amd.models.network import NeuralNetwork
 
