@@ -199,26 +199,6 @@ def test_search_picks_the_same_moves_under_bf16_fp32_engine_and_fp32_module():
     assert s16 >= 0.95 and kl16 < 0.05
 
 
-@pytest.mark.parametrize("batch,live,expect", [(1024, 1024, (16, 4, 124)), (1024, 900, (15, 4, 124)), (1024, 512, (8, 8, 64)),
-                                               (1024, 100, (2, 16, 32)), (1024, 1, (1, 16, 32)), (1024, 0, (16, 4, 124)),
-                                               (200, 64, (1, 7, 4))])
-def test_fp32_shared_fc_plan_follows_the_live_count(batch, live, expect):
-    """The (row blocks, K splits, steps per split) the FC's workgroups deal themselves for a live count: never more
-    workgroups than the launch holds, whole pixel rows per split, no empty split, the static plan for a full batch."""
-    import ctypes
-
-    from alphatriangle_amd.ops import hipbind as hb
-
-    total = 482 if batch == 1024 else 25
-    sk, steps = (4, 124) if batch == 1024 else (2, 16)
-    out = (ctypes.c_int * 3)()
-    getattr(hb.lib(), "atri_split_fc_plan")(hb.i32(live), hb.i32(batch), hb.i32(sk), hb.i32(steps), hb.i32(total), hb.i32(16), out)
-    blocks, splits, per = out[0], out[1], out[2]
-    assert (blocks, splits, per) == expect
-    assert blocks * splits <= (batch + 63) // 64 * sk and per % 4 == 0
-    assert (splits - 1) * per < total <= splits * per
-
-
 @pytest.mark.parametrize("ln_mode", ["affine", "plain", "none"])
 @pytest.mark.parametrize("batch,live,max_splits", [(70, None, 0), (200, 131, 0), (200, 131, 16), (200, 40, 16), (70, None, 16)])
 def test_fp32_shared_fc_kernel_matches_fp64(ln_mode, batch, live, max_splits):
