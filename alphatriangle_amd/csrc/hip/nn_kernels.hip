@@ -560,6 +560,8 @@ __global__ __launch_bounds__(512, 1) void fc_rows_splitk_kernel(const unsigned s
       src[i] = rows + (size_t)min(b0 + r, nB - 1) * HW * 128 + cc * 8;
     }
     const int p0 = s_begin >> 2, p_last = max(p0 + n_feat - 1, 0);
+    // first 128-feature chunk of the "other" features in this split (a split may start behind the body rows)
+    const int k0 = max(s_begin - feat_steps, 0) >> 2;
     // body pixel row f of this split into registers; rows past the split's last one re-read it (loaded, never staged)
     auto issue = [&](int f, uint4 (&v)[CH]) {
       const size_t off = (size_t)min(p0 + f, p_last) * 128;
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(512, 1) void fc_rows_splitk_kernel(const unsigned s
       stage(v[0], 0);
       issue(DEPTH, v[0]);
     } else {
-      stage_other(0, 0);
+      stage_other(k0, 0);
     }
     __syncthreads();
     int i = 0;  // the chunk the consumers multiply now
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(512, 1) void fc_rows_splitk_kernel(const unsigned s
     }
     i = max(n_feat - 1, 0);
     for (; i < n_rows; ++i) {
-      if (i + 1 < n_rows) stage_other(i + 1 - n_feat, (i + 1) & 1);
+      if (i + 1 < n_rows) stage_other(k0 + i + 1 - n_feat, (i + 1) & 1);
       __syncthreads();
     }
     return;

@@ -75,6 +75,8 @@ __global__ __launch_bounds__(512, 1) void fc_rows_split_kernel(const float* __re
       src[i] = rows + (size_t)min(b0 + r, nB - 1) * HW * 128 + cc * 8;
     }
     const int p0 = s_begin >> 2, p_last = max(p0 + n_feat - 1, 0);
+    // first 128-feature chunk of the "other" features in this split (a split may start behind the body rows)
+    const int k0 = max(s_begin - feat_steps, 0) >> 2;
     // body pixel row f of this split into registers; rows past the split's last one re-read it (loaded, never staged)
     auto issue = [&](int f, float4 (&v)[MT][2]) {
       const size_t off = (size_t)min(p0 + f, p_last) * 128;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(512, 1) void fc_rows_split_kernel(const float* __re
       stage(v[0], 0);
       issue(kFcDepth, v[0]);
     } else {
-      stage_other(0, 0);
+      stage_other(k0, 0);
     }
     __syncthreads();
     int i = 0;  // the chunk the consumers multiply now
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void fc_rows_split_kernel(const float* __re
     }
     i = max(n_feat - 1, 0);
     for (; i < n_rows; ++i) {
-      if (i + 1 < n_rows) stage_other(i + 1 - n_feat, (i + 1) & 1);
+      if (i + 1 < n_rows) stage_other(k0 + i + 1 - n_feat, (i + 1) & 1);
       __syncthreads();
     }
     return;

@@ -64,6 +64,9 @@ class NeuralNetwork:
         self.support = torch.linspace(self.v_min, self.v_max, self.num_atoms, device=self.device)
 
         self.engine: Any = None
+        # the precision evaluate_* must deliver: an engine of another precision (the bf16 kernels loaded for a configuration
+        # that has no fp32-grade ones) is kept for callers that ask for it, but is not what evaluate_features runs
+        self.inference_dtype = inference_dtype
         want_engine = use_hip_engine if use_hip_engine is not None else self.device.type == "cuda"
         if want_engine and self.device.type == "cuda":
             from ..ops.inference import InferenceEngine, engine_supports
@@ -72,8 +75,8 @@ class NeuralNetwork:
             if not ok and inference_dtype != "bf16":
                 ok2, _ = engine_supports(model_config, env_config, "bf16")
                 if ok2:
-                    logger.warning("HIP inference engine has no %s path for this config (%s); its bf16 path is loaded instead.",
-                                   inference_dtype, why)
+                    logger.warning("HIP inference engine has no %s path for this config (%s); its bf16 path is loaded for callers "
+                                   "that ask for bf16, evaluate_* keeps to the PyTorch module in fp32.", inference_dtype, why)
                     ok, inference_dtype = True, "bf16"
             if ok:
                 self.engine = InferenceEngine(model_config, env_config, self.device, dtype=inference_dtype)
@@ -117,7 +120,7 @@ class NeuralNetwork:
     @torch.inference_mode()
     def evaluate_features(self, grid: torch.Tensor, other: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """``(policy_logits [B, A] f32, expected_value [B] f32)`` for feature tensors on ``self.device``."""
-        if self.engine is not None:
+        if self.engine is not None and self.engine.dtype == self.inference_dtype:
             return self.engine.forward(grid, other)
         self.model.eval()
         logits, vlogits = self.model(grid.float(), other.float())

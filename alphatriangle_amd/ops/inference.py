@@ -61,6 +61,17 @@ def _pow2(x: int) -> bool:
     return x > 0 and (x & (x - 1)) == 0
 
 
+def _split_flat_ok(rows: int, cols: int) -> bool:
+    """Whether the fp32-grade flat-tile conv kernels hold a board of this size (host-side geometry check of the library;
+    without the library - CPU-only installs - the documented bound is applied: tile rows + halo <= 320, <= 256 cells)."""
+    try:
+        return bool(hb.lib().atri_split_flatconv_supported(int(rows), int(cols)))
+    except Exception:  # noqa: BLE001 - no kernel library on this host
+        tiles = (rows * (cols + 1) + 15) // 16
+        tpw = max(3, (tiles + 3) // 4)
+        return tpw <= 5 and rows * cols <= 256 and 16 * max(tiles, 4 * (tpw - 1)) + 2 * cols + 4 <= 320
+
+
 def engine_supports(mc: ModelConfig, ec: EnvConfig, dtype: str = "bf16") -> tuple[bool, str]:
     """Whether the HIP engine implements this architecture at this precision (else callers use the PyTorch module)."""
     if dtype not in ("bf16", "fp32"):
@@ -68,8 +79,10 @@ def engine_supports(mc: ModelConfig, ec: EnvConfig, dtype: str = "bf16") -> tupl
     if dtype == "fp32":
         # The fp32-grade kernels (csrc/hip/split_*.hip) are written for the reference's default architecture family:
         # 3x3 stem 1 -> 32 -> 64 -> 128, 128-channel residual blocks, d_model 128 / 4 heads, 128-wide dense tail.
-        if ec.ROWS > 8 or ec.COLS > 15:
-            return False, "fp32 kernels need a board of at most 8 x 15 cells"
+        # boards up to 8x15: halo-tile convolutions + one-launch encoder layer; larger boards (up to 256 cells): flat-tile
+        # convolutions (csrc/hip/split_flatconv_kernels.hip) + the row-tiled encoder layer (split_tf_rows_kernels.hip)
+        if (ec.ROWS > 8 or ec.COLS > 15) and not _split_flat_ok(ec.ROWS, ec.COLS):
+            return False, "fp32 kernels need a board of at most 8 x 15 cells or one the flat-tile kernels can hold"
         if list(mc.CONV_FILTERS) != [32, 64, 128]:
             return False, "fp32 kernels need the conv stem 32 / 64 / 128"
         if mc.NUM_RESIDUAL_BLOCKS > 0 and mc.RESIDUAL_BLOCK_FILTERS != 128:
@@ -281,6 +294,9 @@ class InferenceEngine:
         self.heads_fused = False
         self._store: list[torch.Tensor] = []
         self._store_cursor = 0
+        # tests set this to a list: the fp32-grade forward then appends (stage name, copy of the activation rows) after
+        # every body / encoder launch, so a numerics failure names its kernel
+        self.trace: list[tuple[str, torch.Tensor]] | None = None
 
     # ------------------------------------------------------------------ weights
     def _put(self, value: torch.Tensor) -> torch.Tensor:
@@ -541,29 +557,52 @@ class InferenceEngine:
         bufs = self.bufs
         body = self.body_layers
         l1, l2 = body[0][1], body[1][1]
-        hb.call("atri_split_conv_stem", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.ptr(l1.w), hb.i64(l1.lo_off),
+        small = self.H <= 8 and self.W <= 15
+        hb.call("atri_split_conv_stem" if small else "atri_split_flatconv_stem", hb.ptr(grid), hb.ptr(self.w_first), hb.ptr(self.b_first), hb.ptr(l1.w), hb.i64(l1.lo_off),
                 hb.ptr(l1.bias), hb.ptr(l2.w), hb.i64(l2.lo_off), hb.ptr(l2.bias), hb.ptr(l2.post_add), hb.ptr(bufs[0]),
                 hb.i32(B), hb.i32(self.H), hb.i32(self.W), hb.i32(self.c0), hb.i32(l1.cout), hb.i32(l2.cout), hb.i32(self.act))
         cur = 0
         rest = body[2:]
+
+        def note(name: str) -> None:
+            if self.trace is not None:
+                self.trace.append((name, bufs[cur][: B * self.HW * 128].view(B, self.HW, 128).clone()))
+
+        note("stem")
         for li in range(0, len(rest), 2):
             (ka, la), (kb, lb) = rest[li], rest[li + 1]
             assert ka == "res_a" and kb == "res_b"
             dst = (cur + 1) % 3
-            hb.call("atri_split_conv_pair", hb.ptr(bufs[cur]), hb.ptr(la.w), hb.i64(la.lo_off), hb.ptr(la.bias), hb.ptr(lb.w),
+            hb.call("atri_split_conv_pair" if small else "atri_split_flatconv_pair", hb.ptr(bufs[cur]), hb.ptr(la.w), hb.i64(la.lo_off), hb.ptr(la.bias), hb.ptr(lb.w),
                     hb.i64(lb.lo_off), hb.ptr(lb.bias), hb.ptr(lb.post_add), hb.ptr(bufs[dst]), hb.i32(B), hb.i32(self.H),
                     hb.i32(self.W), hb.i32(la.cin), hb.i32(la.act))
             cur = dst
+            note(f"block{li // 2}")
         ln = None
         if self.uses_tf:
             for tl in self.tf_layers:
                 qkv, out, ff1, ff2 = tl["qkv"], tl["out"], tl["ff1"], tl["ff2"]
                 dst = (cur + 1) % 3
+                if self.HW > 128:
+                    # 129..256 tokens: (LN1 + QKV + attention) -> (out-projection + FFN over 128-row tiles)
+                    att = (cur + 2) % 3
+                    hb.call("atri_split_qkv_attn", hb.ptr(bufs[cur]), hb.ptr(bufs[att]), hb.ptr(qkv.w), hb.i64(qkv.lo_off),
+                            hb.ptr(qkv.bias), hb.f32(qkv.ln_eps), hb.i32(B), hb.i32(self.HW))
+                    hb.call("atri_split_proj_ffn_rows", hb.ptr(bufs[att]), hb.ptr(bufs[cur]), hb.ptr(bufs[dst]), hb.ptr(out.w),
+                            hb.i64(out.lo_off), hb.ptr(out.bias), hb.ptr(ff1.w), hb.i64(ff1.lo_off), hb.ptr(ff1.bias), hb.ptr(ff2.w),
+                            hb.i64(ff2.lo_off), hb.ptr(ff2.bias), hb.f32(ff1.ln_eps), hb.i32(B), hb.i32(self.HW), hb.i32(ff1.cout),
+                            hb.i32(self.act))
+                    if self.trace is not None:
+                        self.trace.append((f"attn{len(self.trace)}", bufs[att][: B * self.HW * 128].view(B, self.HW, 128).clone()))
+                    cur = dst
+                    note("layer")
+                    continue
                 hb.call("atri_split_encoder_layer", hb.ptr(bufs[cur]), hb.ptr(bufs[dst]), hb.ptr(qkv.w), hb.i64(qkv.lo_off),
                         hb.ptr(qkv.bias), hb.ptr(out.w), hb.i64(out.lo_off), hb.ptr(out.bias), hb.f32(qkv.ln_eps), hb.ptr(ff1.w),
                         hb.i64(ff1.lo_off), hb.ptr(ff1.bias), hb.ptr(ff2.w), hb.i64(ff2.lo_off), hb.ptr(ff2.bias), hb.f32(ff1.ln_eps),
                         hb.i32(B), hb.i32(self.HW), hb.i32(ff1.cout), hb.i32(self.act))
                 cur = dst
+                note("layer")
             ln = self.final_ln
         g, bt, eps = ln if ln is not None else (None, None, 0.0)
         hb.call("atri_split_fc_rows_dyn", hb.ptr(bufs[cur]), hb.ptr(other), hb.i32(self.other_dim), hb.ptr(g), hb.ptr(bt), hb.f32(eps),

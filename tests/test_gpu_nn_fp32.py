@@ -72,6 +72,82 @@ def test_fp32_engine_stays_within_an_order_of_magnitude_of_pytorch_fp32_rounding
     assert (logits.argmax(1) == ref64_l.argmax(1)).float().mean().item() >= 0.99
 
 
+def _fp64_stages(model: torch.nn.Module, grid: torch.Tensor) -> list[tuple[str, torch.Tensor]]:
+    """Activation rows [B, HW, 128] of an fp64 copy of the module after the stem, every residual block and every encoder
+    layer, named like the entries of ``InferenceEngine.trace``."""
+    m = copy.deepcopy(model).double().eval()
+    out = []
+    with torch.no_grad():
+        x = m.conv_body(grid.double())
+        rows = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], -1, t.shape[1])  # noqa: E731
+        blocks = list(m.res_body)
+        pe = m.pos_encoder.pe[: x.shape[2] * x.shape[3], 0, :]
+        out.append(("stem", rows(x) + (pe if not blocks else 0)))
+        for i, blk in enumerate(blocks):
+            x = blk(x)
+            out.append((f"block{i}", rows(x) + (pe if i == len(blocks) - 1 else 0)))
+        tokens = (rows(x) + pe).permute(1, 0, 2)  # [HW, B, D]
+        for layer in m.transformer_body.layers:
+            tokens = layer(tokens)
+            out.append(("layer", tokens.permute(1, 0, 2)))
+    return out
+
+
+@pytest.mark.parametrize("act", ["ReLU", "GELU"])
+def test_fp32_engine_on_the_12x21_board_matches_fp64_stage_by_stage(act):
+    """The large preset (12x21 board, 252 tokens, 8 encoder layers) on the flat-tile convolutions and the row-tiled
+    encoder kernels: every launch's output against an fp64 evaluation of the module, then logits and values within the
+    bounds of the 8x15 test, for a batch that is no multiple of any tile size and with a device-side live count."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+
+    torch.manual_seed(7)
+    dev = torch.device("cuda")
+    env = EnvConfig.large()
+    mc = ModelConfig.large_transformer(other_dim=8 * env.NUM_SHAPE_SLOTS + 6).model_copy(update={"ACTIVATION_FUNCTION": act})
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev, inference_dtype="fp32")
+    assert net.engine is not None and net.engine.dtype == "fp32", "the fp32-grade HIP engine must cover the 12x21 board"
+    _randomise_norm_layers(net._orig_model)
+    net.sync_inference_weights()
+    batch = 133
+    grid = torch.randint(-1, 2, (batch, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(batch, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    net._orig_model.eval()
+    with torch.no_grad():
+        ref32_l, _ = net._orig_model(grid, other)
+        m64 = copy.deepcopy(net._orig_model).double()
+        ref64_l, ref64_v = m64(grid.double(), other.double())
+    val64 = (torch.softmax(ref64_v, 1) * net.support.double()).sum(1)
+    net.engine.trace = []
+    logits, value = net.evaluate_features(grid, other)
+    torch.cuda.synchronize()
+    trace, net.engine.trace = [t for t in net.engine.trace if not t[0].startswith("attn")], None
+    stages = _fp64_stages(net._orig_model, grid)
+    assert [n for n, _ in trace] == [n for n, _ in stages]
+    for i, ((name, got), (_, want)) in enumerate(zip(trace, stages, strict=True)):
+        err = (got.double() - want).abs().max().item()
+        scale = want.abs().max().item()
+        print(f"  stage {i} {name}: max err {err:.3e} (scale {scale:.2f})")
+        assert err < 3e-5 * max(scale, 1.0), f"stage {i} ({name}) is off by {err} (scale {scale})"
+    eng_err = (logits.double() - ref64_l).abs().max().item()
+    t32_err = (ref32_l.double() - ref64_l).abs().max().item()
+    scale = ref64_l.abs().max().item()
+    veng = (value.double() - val64).abs().max().item()
+    print(f"[large/{act}] logits: engine {eng_err:.3e}, torch fp32 {t32_err:.3e} (scale {scale:.2f}); value: engine {veng:.3e}")
+    assert eng_err < 5e-5 * max(scale, 1.0)
+    assert eng_err < 40 * max(t32_err, 2e-7)
+    assert veng < 5e-5
+    # a live count below the batch: rows beyond it keep their previous contents, rows below it do not change
+    before_l, before_v = logits.clone(), value.clone()
+    live = torch.tensor([70], dtype=torch.int32, device=dev)
+    grid2 = grid.clone()
+    grid2[70:] = 1.0  # would change the results of the dead rows if they were evaluated
+    l2, v2 = net.engine.forward(grid2, other, live=live)
+    torch.cuda.synchronize()
+    # (the shared FC re-deals its K splits for a thin batch, so live rows may differ in the last bits)
+    assert (l2[:70] - before_l[:70]).abs().max().item() < 2e-5 * max(scale, 1.0) and (v2[:70] - before_v[:70]).abs().max().item() < 2e-5
+    assert torch.equal(l2[70:], before_l[70:]) and torch.equal(v2[70:], before_v[70:])
+
+
 def test_fp32_engine_ignores_rows_beyond_the_batch_and_handles_small_boards():
     """Partial workgroups (batch not a multiple of the tile sizes) and a 5x6 board (30 tokens, padded key tiles)."""
     from alphatriangle_amd.models.network import NeuralNetwork
