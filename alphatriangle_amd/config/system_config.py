@@ -65,6 +65,9 @@ class SystemConfig(BaseModel):
     ACTOR_SILENCE_S: float = Field(default=300.0, gt=0, description="Split layout: an actor rank that ships nothing for this long is retired.")
     COLLECTIVE_TIMEOUT_S: float = Field(default=120.0, gt=0, description="Time-out of every data-plane collective (RCCL / gloo).")
     CONTROL_TIMEOUT_S: float = Field(default=60.0, gt=0, description="Time-out of the host-side control plane (agreements, drains).")
+    TRANSFER_TIMEOUT_S: float = Field(default=60.0, gt=0, description="Split layout: deadline of one posted point-to-point transfer; a pair that misses it loses its communicator, the process carries on.")
+    HEARTBEAT_PERIOD_S: float = Field(default=1.0, gt=0, description="Split layout: how often an actor rank renews its heartbeat key in the control store.")
+    HEARTBEAT_STALE_S: float = Field(default=45.0, gt=0, description="Split layout: a learner posts no receive for an actor whose heartbeat is older than this, and retires it.")
     OVERLAP_LEARNER: bool = Field(
         default=True, description="Colocated GPU runs: learner steps on a second HIP stream, concurrent with the search of the move."
     )

@@ -12,7 +12,10 @@ equivalents here:
   between backward and the fused optimizer step.  xGMI is point-to-point, so a
   message this small is latency-bound; it is deliberately a single un-bucketed call;
 * experiences actors -> learner : point-to-point sends of exactly the rows a move produced, announced in the
-  control store first (parallel/experience.py).
+  control store first (parallel/experience.py).  Each (learner, actor) pair owns ONE 2-rank communicator; both sides
+  post their transfers in the order of the pair's announcements, so the two directions never deadlock on it, and
+  every transfer is posted and polled against a deadline (parallel/transport.py): a peer that died costs its pair's
+  communicator, not the process.
 
 ``gloo`` (CPU tests, rehearsals) only ever sees CPU tensors: device tensors are
 staged through host memory with synchronous copies.
@@ -117,7 +120,9 @@ class DistContext:
     control_group: Any = None         # gloo side group for host-side agreement (None: the world group is gloo already)
     learner_control_group: Any = None  # the same for the learner ranks only (split layout with several learners)
     control: ControlPlane | None = None
-    pair_groups: dict[tuple[int, int], tuple[Any, Any]] = field(default_factory=dict)  # (learner, actor) -> (experience, weight) groups
+    pair_groups: dict[tuple[int, int], Any] = field(default_factory=dict)  # (learner, actor) -> the pair's 2-rank group
+    transfer_timeout_s: float = 60.0  # deadline of one posted point-to-point transfer (parallel/transport.py)
+    _transports: dict[tuple[int, int], Any] = field(default_factory=dict)
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -156,6 +161,12 @@ class DistContext:
         src_rank = self.layout.learner_ranks[0] if src is None else src
         self._collective(dist.broadcast, flat_param, src=src_rank, group=self.world_group)
 
+    def broadcast_learners(self, tensor: torch.Tensor) -> None:
+        """Blocking broadcast from the first learner to the other learner ranks (every learner calls this)."""
+        if self.num_learners <= 1 or not self.is_learner:
+            return
+        self._collective(dist.broadcast, tensor, src=self.layout.learner_ranks[0], group=self.learner_group)
+
     def all_gather_records(self, block: torch.Tensor) -> torch.Tensor:
         """All-gather equally sized record blocks ``[n, stride]``; returns ``[world, n, stride]``."""
         out_shape = (self.world_size, *block.shape)
@@ -191,33 +202,38 @@ class DistContext:
         return [float(x) for x in t.cpu().tolist()]
 
     # ------------------------------------------------------------------ point to point (split layout)
-    def _pair(self, learner: int, actor: int, weights: bool) -> Any:
-        try:
-            return self.pair_groups[(learner, actor)][1 if weights else 0]
-        except KeyError:
-            raise RuntimeError(f"no point-to-point group for learner {learner} / actor {actor}") from None
+    def pair_transport(self, learner: int, actor: int) -> Any:
+        """The transport of one (learner, actor) pair (created on first use; see parallel/transport.py)."""
+        key = (learner, actor)
+        tr = self._transports.get(key)
+        if tr is None:
+            from .transport import TorchPairTransport
 
-    def send_to(self, tensor: torch.Tensor, peer: int, *, learner: int, actor: int, weights: bool) -> None:
-        """Blocking-on-stream send of ``tensor`` to ``peer`` on the pair's experience or weight communicator."""
-        grp = self._pair(learner, actor, weights)
-        if self._host_staged() and tensor.is_cuda:
-            tensor = tensor.detach().to("cpu", non_blocking=False)
+            try:
+                grp = self.pair_groups[key]
+            except KeyError:
+                raise RuntimeError(f"no point-to-point group for learner {learner} / actor {actor}") from None
+            tr = self._transports[key] = TorchPairTransport(grp, self._host_staged())
+        return tr
+
+    def send_to(self, tensor: torch.Tensor, peer: int, *, learner: int, actor: int) -> None:
+        """Send ``tensor`` to ``peer`` on the pair's communicator and wait for it (bounded by ``transfer_timeout_s``)."""
+        from .transport import TransferTimeout, wait_for
+
+        tr = self.pair_transport(learner, actor)
         try:
-            dist.send(tensor.contiguous(), dst=peer, group=grp)
-        except RuntimeError as exc:
+            wait_for(tr.post_send(tensor, peer), self.transfer_timeout_s, f"send to rank {peer}", tr)
+        except (RuntimeError, TransferTimeout) as exc:
             raise PeerLostError(f"rank {self.rank}: send to rank {peer} failed ({exc})") from exc
 
-    def recv_from(self, tensor: torch.Tensor, peer: int, *, learner: int, actor: int, weights: bool) -> None:
-        """Receive into ``tensor`` (contiguous) from ``peer`` on the pair's experience or weight communicator."""
-        grp = self._pair(learner, actor, weights)
+    def recv_from(self, tensor: torch.Tensor, peer: int, *, learner: int, actor: int) -> None:
+        """Receive into ``tensor`` (contiguous) from ``peer`` on the pair's communicator, bounded like :meth:`send_to`."""
+        from .transport import TransferTimeout, wait_for
+
+        tr = self.pair_transport(learner, actor)
         try:
-            if self._host_staged() and tensor.is_cuda:
-                host = torch.empty(tensor.shape, dtype=tensor.dtype)
-                dist.recv(host, src=peer, group=grp)
-                tensor.copy_(host, non_blocking=False)
-            else:
-                dist.recv(tensor, src=peer, group=grp)
-        except RuntimeError as exc:
+            wait_for(tr.post_recv(tensor, peer), self.transfer_timeout_s, f"receive from rank {peer}", tr)
+        except (RuntimeError, TransferTimeout) as exc:
             raise PeerLostError(f"rank {self.rank}: receive from rank {peer} failed ({exc})") from exc
 
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
@@ -248,14 +264,14 @@ class DistContext:
             t = torch.zeros(1, dtype=torch.float32, device="cpu" if self._host_staged() else self.device)
             dist.all_reduce(t, group=grp)
         # point-to-point communicators of the split layout: one tiny transfer per pair and direction, in a fixed order
-        for (learner, actor), _groups in sorted(self.pair_groups.items()):
+        for (learner, actor), _group in sorted(self.pair_groups.items()):
             t = torch.zeros(1, dtype=torch.float32, device="cpu" if self._host_staged() else self.device)
             if self.rank == actor:
-                self.send_to(t, learner, learner=learner, actor=actor, weights=False)
-                self.recv_from(t, learner, learner=learner, actor=actor, weights=True)
+                self.send_to(t, learner, learner=learner, actor=actor)
+                self.recv_from(t, learner, learner=learner, actor=actor)
             else:
-                self.recv_from(t, actor, learner=learner, actor=actor, weights=False)
-                self.send_to(t, actor, learner=learner, actor=actor, weights=True)
+                self.recv_from(t, actor, learner=learner, actor=actor)
+                self.send_to(t, actor, learner=learner, actor=actor)
         if not self._host_staged():
             torch.cuda.synchronize(self.device)
 
@@ -289,6 +305,7 @@ def init_distributed(
     init_method: str | None = None,
     timeout_s: float = 120.0,
     control_timeout_s: float = 60.0,
+    transfer_timeout_s: float = 60.0,
 ) -> DistContext:
     """Create the process group (if needed) and the role sub-groups.  Every rank must call this.
 
@@ -328,17 +345,30 @@ def init_distributed(
     if be == "nccl" and 1 < len(roles.learner_ranks) < world_size:
         learner_control_group = dist.new_group(ranks=roles.learner_ranks, backend="gloo",
                                                timeout=datetime.timedelta(seconds=control_timeout_s))
-    # split layout: two 2-rank groups per (learner, actor) pair, one per direction of traffic, so that an experience
-    # shipment and a weight delivery between the same two ranks never queue behind each other on one communicator
-    pair_groups: dict[tuple[int, int], tuple[Any, Any]] = {}
+    # split layout: ONE 2-rank group per (learner, actor) pair.  Both sides post their transfers in the order of the
+    # pair's announcements in the control store (the actor initiates every one of them: a shipment, or a request for the
+    # published weights), so experience up and weights down share the communicator without deadlock.  A transfer on it is
+    # posted, polled and - past transfer_timeout_s - answered by tearing this one communicator down, so the library's
+    # own watchdog must neither fire first (long time-out) nor end the process for it (no asynchronous error handling
+    # for these groups: the setting is read when a group is constructed).
+    pair_groups: dict[tuple[int, int], Any] = {}
     if not roles.colocated:
         n_l = len(roles.learner_ranks)
-        for ai, a in enumerate(roles.actor_ranks):
-            lr = roles.learner_ranks[ai % n_l]
-            g_exp = dist.new_group(ranks=[lr, a])
-            g_w = dist.new_group(ranks=[lr, a])
-            if rank in (lr, a):
-                pair_groups[(lr, a)] = (g_exp, g_w)
+        saved = os.environ.get("TORCH_NCCL_ASYNC_ERROR_HANDLING")
+        if be == "nccl":
+            os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = "0"
+        try:
+            for ai, a in enumerate(roles.actor_ranks):
+                lr = roles.learner_ranks[ai % n_l]
+                grp = dist.new_group(ranks=[lr, a], timeout=datetime.timedelta(seconds=max(timeout_s, 10.0 * transfer_timeout_s) + 3600.0))
+                if rank in (lr, a):
+                    pair_groups[(lr, a)] = grp
+        finally:
+            if be == "nccl":
+                if saved is None:
+                    os.environ.pop("TORCH_NCCL_ASYNC_ERROR_HANDLING", None)
+                else:
+                    os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = saved
     control = None
     try:
         control = ControlPlane(dist.distributed_c10d._get_default_store())
@@ -358,6 +388,7 @@ def init_distributed(
         learner_control_group=learner_control_group,
         control=control,
         pair_groups=pair_groups,
+        transfer_timeout_s=float(transfer_timeout_s),
     )
     logger.info(
         "rank %d/%d backend=%s device=%s role=%s", rank, world_size, be, device, "learner+actor" if roles.colocated else ("learner" if ctx.is_learner else "actor")
@@ -380,5 +411,6 @@ def init_from_env(system_config: Any = None) -> DistContext | None:
     n_learn = getattr(system_config, "NUM_LEARNER_RANKS", 1) if system_config is not None else 1
     timeout_s = float(getattr(system_config, "COLLECTIVE_TIMEOUT_S", 120.0)) if system_config is not None else 120.0
     control_s = float(getattr(system_config, "CONTROL_TIMEOUT_S", 60.0)) if system_config is not None else 60.0
+    transfer_s = float(getattr(system_config, "TRANSFER_TIMEOUT_S", 60.0)) if system_config is not None else 60.0
     return init_distributed(rank, world, local_rank, backend, layout, n_learn, init_method="env://",
-                            timeout_s=timeout_s, control_timeout_s=control_s)
+                            timeout_s=timeout_s, control_timeout_s=control_s, transfer_timeout_s=transfer_s)

@@ -177,6 +177,7 @@ class Trainer:
         self.device = nn_interface.device
         self.autocast_bf16 = bool(autocast_bf16 and self.device.type == "cuda")
         self.grad_sync = grad_sync
+        self.sync_count = 0  # gradient all-reduces entered so far (a failed step is only skipped if it has not entered its own)
         self.world_size = int(world_size)
         use_fused = fused if fused is not None else (self.device.type == "cuda" or grad_sync is not None)
         self.optimizer, self.flat = self._create_optimizer(use_fused)
@@ -322,6 +323,7 @@ class Trainer:
             )
         if self.grad_sync is not None and self.flat is not None:
             self.grad_sync(self.flat.flat_grad)
+            self.sync_count += 1
         clip = self.train_config.GRADIENT_CLIP_VALUE
         if self.flat is None and clip is not None and clip > 0:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
@@ -336,6 +338,24 @@ class Trainer:
             "mean_td_error": td_errors.abs().mean(),
         }
         return info, td_errors
+
+    def skip_step(self) -> bool:
+        """This rank's part of a data-parallel step it has no batch for: a zero gradient into the all-reduce, then the
+        same optimizer and scheduler step as every other rank (which keeps the replicas identical).
+
+        Peers that did get a batch are already waiting in the all-reduce of this step; a rank that simply returned would
+        leave them there until the collective time-out.  Returns False when there is nothing to keep in step with
+        (single learner, or no flat gradient buffer)."""
+        if self.grad_sync is None or self.flat is None:
+            return False
+        self.flat.release_grads()
+        self.flat.flat_grad.zero_()
+        self.grad_sync(self.flat.flat_grad)
+        self.sync_count += 1
+        self.optimizer.step()
+        if self.scheduler:
+            self.scheduler.step()
+        return True
 
     def train_step(self, per_sample: PERBatchSample | TensorBatch) -> tuple[dict[str, float], np.ndarray] | None:
         """Reference-shaped step: returns ``(loss_info floats, td_errors ndarray)`` or ``None`` on an empty batch."""

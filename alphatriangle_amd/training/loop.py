@@ -143,6 +143,7 @@ class TrainingLoop:
         self.training_complete = False
         self.training_exception: Exception | None = None
         self.peer_lost = False
+        self.skipped_steps = 0  # data-parallel steps this rank took part in without a batch of its own
         self._announced_ready = False
 
         self.source: SelfPlaySource = self._build_source()
@@ -328,14 +329,40 @@ class TrainingLoop:
                     lo.get("value_loss", 0.0), self.trainer.get_current_lr() if self.trainer is not None else 0.0)
 
     def _learner_step(self) -> bool:
-        """Sample, optimise, re-prioritise, report; advance ``global_step`` and fire the cadences."""
-        sample = self.buffer.sample(self.train_config.BATCH_SIZE, current_train_step=self.global_step)
-        if not sample:
-            return False
-        outcome = self.trainer.train_step(sample)
+        """Sample, optimise, re-prioritise, report; advance ``global_step`` and fire the cadences.
+
+        Returns False when no optimizer step was taken.  With data-parallel learners a rank whose own step fails (no
+        sample, a batch that cannot be prepared, an exception in forward / backward) still takes part in the step of
+        the others with a zero gradient (:meth:`Trainer.skip_step`) and counts it: the ranks agreed on a number of steps
+        for this round, and each of those steps is one all-reduce that every rank has to enter."""
+        outcome = None
+        sample = None
+        lockstep = self.dist is not None and self.dist.is_learner and self.dist.num_learners > 1
+        syncs_before = int(getattr(self.trainer, "sync_count", 0)) if lockstep else 0
+        try:
+            sample = self.buffer.sample(self.train_config.BATCH_SIZE, current_train_step=self.global_step)
+            if sample:
+                outcome = self.trainer.train_step(sample)
+        except Exception as exc:
+            from ..parallel.dist import PeerLostError
+
+            if not lockstep or isinstance(exc, PeerLostError):
+                raise  # a single learner has nobody to keep in step with: the failure ends the run as it always did
+            logger.error("learner step %d failed on this rank: %s", self.global_step + 1, exc, exc_info=True)
         if not outcome:
-            logger.warning("learner step %d produced no result.", self.global_step + 1)
-            return False
+            entered = lockstep and int(getattr(self.trainer, "sync_count", 0)) > syncs_before  # its all-reduce already happened
+            if not lockstep or (not entered and not self.trainer.skip_step()):
+                if sample:
+                    logger.warning("learner step %d produced no result.", self.global_step + 1)
+                return False
+            # kept in step with the other learners on their gradients alone
+            self.skipped_steps += 1
+            self.global_step += 1
+            logger.warning("learner step %d: no batch on this rank, stepped on the other ranks' gradients.", self.global_step)
+            self._emit("Learner/Skipped_Steps", self.skipped_steps)
+            for cadence in self.cadences:
+                cadence.tick(self.global_step)
+            return True
         losses, td_errors = outcome
         self.global_step += 1
         if self.global_step == self.initial_global_step + 1:

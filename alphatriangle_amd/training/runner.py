@@ -62,8 +62,37 @@ def _load_and_apply_initial_state(components: TrainingComponents) -> TrainingLoo
         logger.info("Buffer size after rebuild: %d", len(components.buffer))
     else:
         logger.info("No buffer data loaded.")
+    _align_learner_replicas(components, loop)
     components.nn.model.train()
     return loop
+
+
+def _align_learner_replicas(components: TrainingComponents, loop: TrainingLoop) -> None:
+    """Data-parallel learners all-reduce gradients and never exchange parameters afterwards, so they have to START from
+    the same parameters, statistics and step count: the first learner's are sent to the others once (a different seed
+    per rank, or a checkpoint only one rank found, would otherwise leave the replicas apart for the whole run)."""
+    ctx = components.dist
+    if ctx is None or components.trainer is None or not ctx.is_learner or ctx.num_learners <= 1:
+        return
+    import torch
+
+    from ..parallel.weights import WeightWire
+
+    wire = WeightWire(components.nn._orig_model)
+    lead = ctx.layout.learner_ranks[0]
+    if ctx.rank == lead:
+        wire.pack()
+    ctx.broadcast_learners(wire.buffer)
+    counters = torch.tensor([loop.global_step, loop.episodes_played, loop.total_simulations_run], dtype=torch.float64,
+                            device=wire.buffer.device)
+    ctx.broadcast_learners(counters)
+    if ctx.rank != lead:
+        wire.unpack()
+        step, episodes, sims = (int(v) for v in counters.tolist())
+        if step != loop.global_step:
+            logger.warning("rank %d resumes at the first learner's step %d (its own state was at %d).", ctx.rank, step, loop.global_step)
+            loop.set_initial_state(step, episodes, sims)
+        components.nn.sync_inference_weights()
 
 
 def _save_final_state(loop: TrainingLoop) -> None:

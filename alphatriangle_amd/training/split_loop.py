@@ -5,18 +5,22 @@ objects; its learner blocks on every weight push (alphatriangle/training/loop.py
 alphatriangle/training/worker_manager.py:169-209).  On one MI355X node the roles are ranks
 of one RCCL job and neither side ever waits for the other's compute:
 
-  actor rank    loop: [stop?] -> [newer weights published? request them, receive, re-pack] ->
-                play one move of every game -> announce + send this move's records.
-  learner rank  loop: take every announced shipment into the HBM replay -> serve weight
-                requests -> a few optimizer steps -> publish (version bump in the control
-                store) every ``WORKER_UPDATE_FREQ_STEPS`` steps.
+  actor rank    loop: [stop?] -> [weights asked for a move ago: take them, re-pack] -> [newer
+                version published? ask for it] -> play one move of every game -> announce +
+                send this move's records.
+  learner rank  loop: serve every announced operation (shipments into the HBM replay, weight
+                requests from the published snapshot) -> a few optimizer steps -> publish
+                (version bump in the control store) every ``WORKER_UPDATE_FREQ_STEPS`` steps.
 
 Nothing here is a collective over actors and learners together.  Every transfer is a
-point-to-point send / receive on a communicator of its own (one per pair and direction), and
-it is only posted after both sides have said so in the control store, so a transfer never
-hangs on a peer that is busy, and a peer that died is noticed by its silence: the learner
-retires the actor and trains on with the others (alphatriangle/training/worker_manager.py:153-159
-removes a dead worker the same way); an actor whose learner is gone leaves with an error.
+point-to-point send / receive on the one communicator of its (learner, actor) pair, initiated by
+the actor and announced in the control store before either side posts it (parallel/experience.py),
+so a transfer never hangs on a peer that is busy.  An actor asks for a newly published weight
+version at the start of a move and takes it at the start of the next one: the delivery happens
+while it searches.  A peer that died is noticed by its heartbeat or by a transfer that misses
+its deadline: the learner retires the actor - at the cost of that pair's communicator at most -
+and trains on with the others (alphatriangle/training/worker_manager.py:153-159 removes a dead
+worker the same way); an actor whose learner is gone leaves with an error.
 Several learner ranks keep their optimizer steps in lock-step through a host-side agreement
 and all-reduce their flat gradients.
 """
@@ -145,86 +149,71 @@ class SplitRoleLoop(TrainingLoop):
         self.rows_ingested = 0
         self.busy_s = 0.0            # learner: time spent in optimizer steps (the rest is polling / ingest / idle)
         self._seen_version = 0       # actor: last weight version received; lead learner: last version announced
-        self._served: dict[int, int] = {}
+        self._packed_version = 0     # learners: the version the wire buffer holds
+        self.version_lag_sum = 0     # actor: published version minus the version played with, summed over moves
         self.outbox: ExperienceOutbox | None = None
         if ctx.is_actor:
             if source is None:
                 raise ValueError("actor ranks need an ExperienceSource")
             max_rows = int(self.sys.GAMES_PER_GPU) * (int(self.train_config.N_STEP_RETURNS) + 1)
-            self.outbox = ExperienceOutbox(ctx, self.layout, dev, max(max_rows, int(self.sys.SHIP_CAPACITY)))
+            self.outbox = ExperienceOutbox(ctx, self.layout, dev, max(max_rows, int(self.sys.SHIP_CAPACITY)),
+                                           heartbeat_period_s=float(self.sys.HEARTBEAT_PERIOD_S))
         else:
-            self.inbox = ExperienceInbox(ctx, self.layout, dev, silence_s=float(self.sys.ACTOR_SILENCE_S))
+            self.inbox = ExperienceInbox(ctx, self.layout, dev, silence_s=float(self.sys.ACTOR_SILENCE_S),
+                                         heartbeat_stale_s=float(self.sys.HEARTBEAT_STALE_S), weights_provider=self._weights_for)
 
     def _build_source(self) -> Any:
         self.worker_manager = None
         return _RemoteActors(self)
 
-    # ------------------------------------------------------------------ weights: lead learner side
+    # ------------------------------------------------------------------ weights: learner side
     def _announce_weights(self, step: int) -> None:
         """Snapshot the parameters into the wire buffer and bump the published version (no transfer yet)."""
         if self.ctx.rank != self.lead:
             return
         self.wire.pack()
         self._seen_version += 1
+        self._packed_version = self._seen_version
         cp = self.ctx.control
         cp.put("weights/step", step)
         cp.put("weights/version", self._seen_version)
 
-    def _serve_weight_requests(self) -> int:
-        """Send the current snapshot to every actor that asked for a version it does not have yet."""
-        if self.ctx.rank != self.lead or self._seen_version == 0:
-            return 0
-        cp = self.ctx.control
-        sent = 0
-        for a in self.ctx.layout.actor_ranks:
-            want = int(cp.peek(f"weights/want/{a}", 0) or 0)
-            if want > self._served.get(a, 0):
-                learner = assigned_learner(self.ctx, a)
-                if learner != self.lead:
-                    continue  # pairs exist only between an actor and its own learner; that learner relays (below)
-                try:
-                    self.ctx.send_to(self.wire.buffer, a, learner=self.lead, actor=a, weights=True)
-                except PeerLostError:
-                    logger.error("actor rank %d did not take the weights it asked for; skipping it.", a)
-                self._served[a] = want
-                sent += 1
-        return sent
+    def _weights_for(self, wanted: int) -> torch.Tensor | None:
+        """The buffer that answers an actor's request for version ``wanted`` (``None``: not published yet).
 
-    def _relay_weight_requests(self) -> int:
-        """Non-lead learners hold the same parameters (lock-step data parallel) and serve their own actors."""
-        if self.ctx.rank == self.lead or not self.ctx.is_learner:
-            return 0
-        cp = self.ctx.control
-        version = int(cp.peek("weights/version", 0) or 0)
-        sent = 0
-        for feed in (self.inbox.feeds if self.inbox else []):
-            want = int(cp.peek(f"weights/want/{feed.rank}", 0) or 0)
-            if want > self._served.get(feed.rank, 0) and want <= version:
-                self.wire.pack()
-                try:
-                    self.ctx.send_to(self.wire.buffer, feed.rank, learner=self.ctx.rank, actor=feed.rank, weights=True)
-                except PeerLostError:
-                    logger.error("actor rank %d did not take the weights it asked for; skipping it.", feed.rank)
-                self._served[feed.rank] = want
-                sent += 1
-        return sent
+        The lead learner serves the snapshot it took when it published.  Every other learner holds the same parameters
+        (lock-step data parallel) and snapshots its own copy the first time a published version is asked for."""
+        if self.ctx.rank == self.lead:
+            return self.wire.buffer if 0 < wanted <= self._seen_version else None
+        version = int(self.ctx.control.peek("weights/version", 0) or 0)
+        if wanted > version or version == 0:
+            return None
+        if self._packed_version < version:
+            self.wire.pack()
+            self._packed_version = version
+        return self.wire.buffer
 
     # ------------------------------------------------------------------ weights: actor side
-    def _take_new_weights(self) -> bool:
-        cp = self.ctx.control
-        version = int(cp.peek("weights/version", 0) or 0)
-        if version <= self._seen_version:
+    def _apply_requested_weights(self) -> bool:
+        """Take the version asked for earlier (served while the last move was searched) and re-pack the evaluator."""
+        assert self.outbox is not None and self.producer is not None
+        if not self.outbox.weights_pending():
             return False
-        me = self.ctx.rank
-        learner = assigned_learner(self.ctx, me)
-        cp.put(f"weights/want/{me}", version)
-        self.ctx.recv_from(self.wire.buffer, learner, learner=learner, actor=me, weights=True)
+        version = self.outbox.take_weights()
         self.wire.unpack()
-        step = int(cp.peek("weights/step", 0) or 0)
-        assert self.producer is not None
+        step = int(self.ctx.control.peek("weights/step", 0) or 0)
         self.producer.sync_weights(step)  # re-folds / re-packs the evaluator's weights in place
         self._seen_version = version
         self.weight_update_count += 1
+        return True
+
+    def _request_new_weights(self) -> bool:
+        """Ask for the published version if it is newer than what this actor has or has already asked for."""
+        assert self.outbox is not None
+        version = int(self.ctx.control.peek("weights/version", 0) or 0)
+        if version <= self._seen_version or self.outbox.weights_pending():
+            return False
+        self.outbox.request_weights(version, self.wire.buffer)
         return True
 
     # ------------------------------------------------------------------ learner
@@ -287,8 +276,9 @@ class SplitRoleLoop(TrainingLoop):
                 if target is not None and self.global_step >= target:
                     self.training_complete = True
                     self.request_stop()
+                served_before = self.inbox.weights_served
                 got = self._ingest()
-                served = self._serve_weight_requests() + self._relay_weight_requests()
+                served = self.inbox.weights_served - served_before
                 if self.inbox.feeds and all(f.retired for f in self.inbox.feeds):
                     raise PeerLostError("every actor rank that feeds this learner has gone silent")
                 quota = self._negotiate()
@@ -319,10 +309,9 @@ class SplitRoleLoop(TrainingLoop):
         deadline = time.monotonic() + patience_s
         try:
             while not self.inbox.drained() and time.monotonic() < deadline:
-                if not self._ingest() and not (self._serve_weight_requests() + self._relay_weight_requests()):
+                if not self._ingest():
                     time.sleep(0.01)
-            self._serve_weight_requests()
-            self._relay_weight_requests()
+            self.inbox.finish_sends()
         except PeerLostError as exc:
             logger.error("drain ended early: %s", exc)
         if not self.inbox.drained():
@@ -338,10 +327,14 @@ class SplitRoleLoop(TrainingLoop):
                 break
             time.sleep(0.01)
         try:
+            if self._request_new_weights():  # the first version is waited for: every actor starts from the learner's parameters
+                self._apply_requested_weights()
             while not self.stop_requested.is_set():
                 if cp.peek("stop", 0):
                     break
-                self._take_new_weights()
+                self._apply_requested_weights()  # asked for at the start of the previous move: served meanwhile
+                self._request_new_weights()      # arrives under this move's search, used from the next move on
+                self.version_lag_sum += max(0, int(cp.peek("weights/version", 0) or 0) - self._seen_version)
                 records, counters = self.producer.produce()
                 report = getattr(self.producer, "last_report", None)
                 if report is not None:  # per-episode and per-game-step metrics go to this rank's own metric stream
@@ -368,6 +361,8 @@ class SplitRoleLoop(TrainingLoop):
             "rank": ctx.rank, "role": "learner" if ctx.is_learner else "actor", "wall_seconds": round(wall, 3), "rounds": self.rounds,
             "learner_steps": self.global_step - self.initial_global_step, "learner_busy_fraction": round(self.busy_s / wall, 4),
             "rows_ingested": self.rows_ingested, "moves_played": self.moves_played, "weight_versions": self.weight_update_count,
+            "mean_weight_version_lag": round(self.version_lag_sum / max(self.rounds, 1), 3) if ctx.is_actor else None,
+            "weights_served": self.inbox.weights_served if self.inbox is not None else None,
             "actors_retired": [f.rank for f in self.inbox.feeds if f.retired] if self.inbox is not None else [],
             "complete": bool(self.training_complete),
         }

@@ -57,3 +57,31 @@ def test_bench_prints_exactly_one_json_line_with_the_contract_fields(dtype):
 def test_bench_metric_string_is_the_one_baseline_json_names():
     metric = json.loads((ROOT / "BASELINE.json").read_text())["metric"]
     assert f'"metric": "{metric}"' in (ROOT / "bench.py").read_text()
+
+
+def test_all_configs_appends_the_other_presets_and_leaves_the_headline_alone():
+    """--all-configs (cpu engine stand-in): the extra key lists the other configurations, the headline fields keep their
+    meaning (value = games / time per step of the timed run) and the line says which backend and precision it ran on."""
+    res = _run(["--engine", "cpu", "--steps", "2", "--warmup", "1", "--games", "2", "--sims", "4", "--all-configs"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert REQUIRED | {"dtype_detail", "backend", "ranks_seen", "configs"} <= set(out)
+    assert out["backend"] == "none" and out["ranks_seen"] == 1 and "fp32" in out["dtype_detail"]
+    assert abs(out["value"] - 2 / (out["ms_per_step"] / 1e3)) / out["value"] < 0.02
+    assert len(out["configs"]) >= 2
+    for c in out["configs"]:
+        assert {"preset", "sims", "dtype", "moves_per_s"} <= set(c) and c["moves_per_s"] > 0
+    assert "all-reduce" not in out["config"]["parallelism"]  # one rank: no collective is claimed
+    plain = json.loads([ln for ln in _run(["--engine", "cpu", "--steps", "2", "--warmup", "1", "--games", "2", "--sims", "4"]).stdout.splitlines() if ln.strip()][0])
+    assert "configs" not in plain and set(plain) == set(out) - {"configs"}
+
+
+@pytest.mark.gpu
+def test_bench_line_names_its_precision_scheme():
+    res = _run(["--steps", "1", "--warmup", "1", "--games", "256", "--sims", "8", "--train-steps", "1"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
+    assert out["dtype"] == "fp32" and out["dtype_detail"].startswith("bf16x3") and "16-bit operands" in out["dtype_detail"]
+    assert out["backend"] == "none" and out["ranks_seen"] == 1

@@ -43,6 +43,25 @@ def test_bench_gpus_2_starts_two_ranks_itself_and_prints_one_line():
     assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] / 1e3)) / out["value"] < 0.02
 
 
+def test_bench_split_layout_three_ranks_prints_one_line_with_the_learner_figures():
+    """`bench.py --gpus 3 --layout split --engine cpu`: two actor ranks + one learner rank over gloo, one JSON line whose
+    value is the summed moves/s of the ACTOR ranks and which carries the learner's own figures."""
+    res = subprocess.run(
+        [sys.executable, str(ROOT / "bench.py"), "--gpus", "3", "--layout", "split", "--engine", "cpu", "--steps", "8", "--warmup", "2",
+         "--games", "2", "--sims", "4", "--batch", "4"],
+        cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["steps"] == 8 and out["warmup"] == 2 and out["backend"] == "gloo" and out["ranks_seen"] == 3
+    assert out["config"]["actor_ranks"] == 2 and out["config"]["learner_ranks"] == 1 and out["config"]["parallelism"].startswith("split")
+    # two actors x two games per timed move of the slowest actor
+    assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] / 1e3)) / out["value"] < 0.02
+    assert out["learner_steps"] > 0 and out["trainer_samples_per_sec"] > 0 and 0 < out["learner_busy_fraction"] <= 1
+    assert out["mean_weight_version_lag"] >= 0 and out["actors_retired"] == 0
+
+
 def test_bench_refuses_a_gpus_flag_that_contradicts_the_launcher():
     env = _clean_env()
     env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
@@ -123,6 +142,40 @@ def _late_ready(rank, world, init, root):
 
 def test_colocated_data_parallel_ranks_agree_on_readiness(tmp_path):
     _spawn(_late_ready, 2, str(tmp_path))
+
+
+def _one_rank_has_no_batch(rank, world, init, root):
+    """Rank 1's replay refuses to hand out its third and fourth batch.  The ranks agreed on their step counts before, so
+    rank 0 is already waiting in the gradient all-reduce of those steps: rank 1 has to join them with a zero gradient."""
+    if rank == 1:
+        from alphatriangle_amd.rl.core import buffer as buffer_mod
+
+        orig = buffer_mod.ExperienceBuffer.sample
+        calls = {"n": 0}
+
+        def sample(self, *a, **k):  # noqa: ANN001, ANN002, ANN003
+            calls["n"] += 1
+            return None if calls["n"] in (3, 4) else orig(self, *a, **k)
+
+        buffer_mod.ExperienceBuffer.sample = sample
+    t0 = time.monotonic()
+    code, ctx = _run_rank(rank, world, init, root, lambda r: {"MAX_TRAINING_STEPS": 8}, lambda r: {}, timeout_s=30.0)
+    assert code == 0, f"rank {rank} exited with {code}"
+    assert time.monotonic() - t0 < 60, "a rank without a batch must not strand the others in the all-reduce"
+    from alphatriangle_amd.stats import Serializer
+
+    ck = Serializer().load_checkpoint(Path(root) / "t" / "runs" / ("r0" if rank == 0 else f"r0_rank{rank}") / "checkpoints" / "latest.pkl")
+    assert ck.global_step == 8, f"rank {rank} stopped at step {ck.global_step}"  # both ranks counted the same eight optimizer steps
+    # the replicas went through the same eight updates: identical parameters without any broadcast
+    flat = torch.cat([v.reshape(-1).float() for v in ck.model_state_dict.values() if v.dtype.is_floating_point])
+    other = flat.clone()
+    ctx.broadcast_weights(other, src=0)
+    assert torch.allclose(other, flat, atol=1e-7), f"rank {rank}: replicas differ by {(other - flat).abs().max().item():.3e}"
+    ctx.shutdown()
+
+
+def test_a_data_parallel_rank_without_a_batch_still_enters_the_all_reduce(tmp_path):
+    _spawn(_one_rank_has_no_batch, 2, str(tmp_path))
 
 
 def _one_rank_leaves(rank, world, init, root):

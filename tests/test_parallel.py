@@ -187,3 +187,162 @@ def _split_training(rank, world, init, root):
 def test_split_role_training_loop_three_ranks():
     with tempfile.TemporaryDirectory() as root:
         _spawn(_split_training, 3, root)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Peer loss whose failure surfaces later than the call (what RCCL does: a send / receive returns once it is enqueued).
+class _DictStore:
+    """In-process stand-in of the rendezvous store (add / set / get / check)."""
+
+    def __init__(self):
+        self.d: dict[str, bytes] = {}
+
+    def add(self, key, amount):
+        v = int(self.d.get(key, b"0")) + int(amount)
+        self.d[key] = str(v).encode()
+        return v
+
+    def set(self, key, value):
+        self.d[key] = str(value).encode()
+
+    def get(self, key):
+        return self.d[key]
+
+    def check(self, keys):
+        return all(k in self.d for k in keys)
+
+
+class _StubTransfer:
+    def __init__(self, completes: bool, on_finish=None):
+        self.completes, self.on_finish, self.finished = completes, on_finish, False
+
+    def done(self):
+        return self.completes
+
+    def finish(self, timeout_s=0.0):
+        self.finished = True
+        if self.on_finish:
+            self.on_finish()
+
+
+class _StubTransport:
+    """post_* always succeeds at once; whether the transfer ever completes is decided by ``alive``."""
+
+    def __init__(self):
+        self.alive, self.aborts, self.recvs, self.sends = True, 0, 0, 0
+
+    def post_recv(self, tensor, peer):
+        self.recvs += 1
+        return _StubTransfer(self.alive, on_finish=lambda: tensor.fill_(float(peer)))
+
+    def post_send(self, tensor, peer):
+        self.sends += 1
+        return _StubTransfer(self.alive)
+
+    def abort(self):
+        self.aborts += 1
+
+
+def _stub_ctx(rank, control):
+    from types import SimpleNamespace
+
+    layout = RoleLayout.build(3, "split", 1)
+    return SimpleNamespace(rank=rank, control=control, layout=layout, backend="gloo", transfer_timeout_s=0.2,
+                           pair_transport=lambda learner, actor: (_ for _ in ()).throw(AssertionError("transport must be injected")))
+
+
+def _announce_shipment(cp, actor, k, rows):
+    slot = k % 64
+    cp.put(f"op/{actor}/{slot}/kind", 1)
+    cp.put(f"op/{actor}/{slot}/rows", rows)
+    for f in ("episodes", "simulations", "moves"):
+        cp.put(f"op/{actor}/{slot}/{f}", 1)
+    cp.add(f"op/{actor}/n", 1)
+
+
+def test_learner_survives_a_transfer_whose_failure_surfaces_after_the_call():
+    """Actor 2 announces a shipment, its receive is posted without error - and never completes (the actor died after
+    announcing).  The learner must give up after the transfer deadline, tear down THAT pair's communicator once, retire
+    the actor, and keep serving actor 1."""
+    import time
+
+    from alphatriangle_amd.parallel.dist import ControlPlane
+
+    cp = ControlPlane(_DictStore())
+    layout = RecordLayout(grid=9, other=14, policy=9)
+    t1, t2 = _StubTransport(), _StubTransport()
+    inbox = ExperienceInbox(_stub_ctx(0, cp), layout, torch.device("cpu"), silence_s=300.0, heartbeat_stale_s=300.0,
+                            transports={1: t1, 2: t2})
+    for a in (1, 2):
+        cp.add(f"hb/{a}", 1)
+    _announce_shipment(cp, 1, 1, 3)
+    _announce_shipment(cp, 2, 1, 4)
+    t2.alive = False  # from here on nothing actor 2 is part of ever completes
+    t0 = time.monotonic()
+    got = inbox.poll()
+    assert time.monotonic() - t0 < 5.0  # bounded by the 0.2 s transfer deadline, not by a library time-out
+    assert [s.actor for s in got] == [1] and got[0].records.shape == (3, layout.stride) and got[0].records.eq(1).all()
+    assert t2.recvs == 1 and t2.aborts == 1 and t1.aborts == 0
+    retired = {f.rank: f.retired for f in inbox.feeds}
+    assert retired == {1: False, 2: True} and inbox.active_actors() == 1
+    assert cp.peek("ack/1") == 1 and cp.peek("ack/2", 0) == 0  # the lost shipment is not acknowledged
+    # the survivor keeps being served, the retired pair is never touched again
+    _announce_shipment(cp, 1, 2, 2)
+    _announce_shipment(cp, 2, 2, 2)
+    got = inbox.poll()
+    assert [s.actor for s in got] == [1] and t2.recvs == 1 and t2.aborts == 1
+
+
+def test_no_receive_is_posted_for_an_actor_whose_heartbeat_is_stale():
+    """A stale heartbeat retires the actor BEFORE anything is posted on its communicator (which therefore stays intact)."""
+    import time
+
+    from alphatriangle_amd.parallel.dist import ControlPlane
+
+    cp = ControlPlane(_DictStore())
+    layout = RecordLayout(grid=9, other=14, policy=9)
+    t1, t2 = _StubTransport(), _StubTransport()
+    inbox = ExperienceInbox(_stub_ctx(0, cp), layout, torch.device("cpu"), silence_s=300.0, heartbeat_stale_s=0.15,
+                            transports={1: t1, 2: t2})
+    for a in (1, 2):
+        cp.add(f"hb/{a}", 1)
+    assert inbox.poll() == []          # both heartbeats seen
+    time.sleep(0.25)
+    cp.add("hb/1", 1)                  # actor 1 is alive, actor 2 has stopped beating
+    _announce_shipment(cp, 1, 1, 1)
+    _announce_shipment(cp, 2, 1, 1)
+    got = inbox.poll()
+    assert [s.actor for s in got] == [1]
+    assert t2.recvs == 0 and t2.aborts == 0 and {f.rank: f.retired for f in inbox.feeds} == {1: False, 2: True}
+
+
+def test_a_weight_delivery_nobody_takes_costs_only_its_own_pair():
+    """Actor 2 asks for weights and dies: the learner's send is posted, never completes, and is given up on later polls;
+    actor 1's request is served."""
+    import time
+
+    from alphatriangle_amd.parallel.dist import ControlPlane
+
+    cp = ControlPlane(_DictStore())
+    layout = RecordLayout(grid=9, other=14, policy=9)
+    t1, t2 = _StubTransport(), _StubTransport()
+    wire = torch.arange(5.0)
+    inbox = ExperienceInbox(_stub_ctx(0, cp), layout, torch.device("cpu"), silence_s=300.0, heartbeat_stale_s=300.0,
+                            weights_provider=lambda wanted: wire if wanted <= 1 else None, transports={1: t1, 2: t2})
+    for a in (1, 2):
+        cp.add(f"hb/{a}", 1)
+        slot = 1 % 64
+        cp.put(f"op/{a}/{slot}/kind", 2)
+        cp.put(f"op/{a}/{slot}/rows", 1)  # version 1
+        cp.add(f"op/{a}/n", 1)
+    t2.alive = False
+    assert inbox.poll() == [] and t1.sends == 1 and t2.sends == 1 and inbox.weights_served == 2
+    time.sleep(0.3)
+    inbox.poll()
+    assert t2.aborts == 1 and t1.aborts == 0 and {f.rank: f.retired for f in inbox.feeds} == {1: False, 2: True}
+    # a request for a version that is not published yet stays queued instead of being answered with stale weights
+    cp.put(f"op/1/{2 % 64}/kind", 2)
+    cp.put(f"op/1/{2 % 64}/rows", 2)
+    cp.add("op/1/n", 1)
+    inbox.poll()
+    assert t1.sends == 1 and inbox.feeds[0].taken == 1
