@@ -33,9 +33,10 @@ __device__ __forceinline__ short8 pack_bf16x8(float a0, float a1, float a2, floa
   return __builtin_bit_cast(short8, u);
 }
 
-// fp32 -> (hi, lo) bf16 pair with hi + lo carrying 16 significant bits of x: hi = bf16(x), lo = bf16(x - hi).
-// Products of such pairs on the bf16 matrix cores (hi*hi + lo*hi + hi*lo, fp32 accumulation) are the fp32-grade
-// GEMM of the split_* kernels.  A NaN or an infinity stays visible: hi carries it, lo becomes NaN.
+// fp32 -> (hi, lo) bf16 pair with hi + lo carrying 16 significant bits of x: hi = bf16(x), lo = bf16(x - hi).  Products of
+// such pairs on the bf16 matrix cores (hi*hi + lo*hi + hi*lo, fp32 accumulation) are the fp32-grade GEMMs of the LEARNER
+// kernels (learner_gemm_kernels.hip, learner_attn_kernels.hip): gradients span fp32's whole exponent range, which bf16
+// keeps and fp16 does not.  A NaN or an infinity stays visible: hi carries it, lo becomes NaN.
 __device__ __forceinline__ void split_bf16x8(const float (&v)[8], short8& hi, short8& lo) {
   hi = pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
   float r[8];
@@ -43,11 +44,68 @@ __device__ __forceinline__ void split_bf16x8(const float (&v)[8], short8& hi, sh
   for (int j = 0; j < 8; ++j) r[j] = v[j] - bf16_to_float((unsigned short)hi[j]);
   lo = pack_bf16x8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
 }
-// acc += A B for operands given as (hi, lo) pairs: three MFMA passes, smallest terms first.
+// acc += A B for operands given as (hi, lo) bf16 pairs: three MFMA passes, smallest terms first.
 __device__ __forceinline__ float4v mfma_split(const short8& ah, const short8& al, const short8& bh, const short8& bl, float4v acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+// Operand format of the fp32-grade INFERENCE kernels (split_*.hip), chosen when the library is built:
+//   1  fp16 pairs (default): hi = f16(x), lo = f16(x - hi) - 22 significant bits per operand for |x| >= 2^-3, an absolute
+//      error of at most 2^-25 below that (fp16's subnormal spacing), values beyond 65504 become infinities (and surface
+//      through the engine's non-finite census).  Activations of this network are O(1 .. 100) and probabilities are
+//      taken relative to their row maximum, so the range is not a constraint; measured against an fp64 evaluation the
+//      logits are within 0.6 - 1.2e-6, as close as PyTorch's own fp32 path (0.5 - 2.3e-6).
+//   0  bf16 pairs: 16 significant bits, fp32's exponent range (logits within 4 - 6e-6); the first form of these kernels.
+// Either way a product is three MFMA passes hi*hi + lo*hi + hi*lo with fp32 accumulation, at the same speed (the f16
+// and bf16 MFMA of one shape take the same cycles).  The host packs weights in the same format (ops/inference.py
+// reads atri_split_operand_format()).
+#ifndef ATRI_SPLIT_F16
+#define ATRI_SPLIT_F16 1
+#endif
+constexpr bool kSplitF16 = ATRI_SPLIT_F16 != 0;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8v;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+
+// Two floats -> one dword of two split operands (first value in bits 0..15), round to nearest even.
+__device__ __forceinline__ unsigned int split_pack2(float a, float b) {
+  if constexpr (kSplitF16) {
+    float2v v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, half2v));
+  } else {
+    return pack_bf16x2(a, b);
+  }
+}
+__device__ __forceinline__ float split_unpack(unsigned short h) {
+  if constexpr (kSplitF16) {
+    return (float)__builtin_bit_cast(_Float16, h);
+  } else {
+    return bf16_to_float(h);
+  }
+}
+__device__ __forceinline__ float4v split_mma(const short8& a, const short8& b, float4v acc) {
+  if constexpr (kSplitF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, a), __builtin_bit_cast(half8v, b), acc, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
+}
+// fp32 -> (hi, lo) pair of split operands with hi + lo ~= x.
+__device__ __forceinline__ void split_op8(const float (&v)[8], short8& hi, short8& lo) {
+  const uint4v uh = {split_pack2(v[0], v[1]), split_pack2(v[2], v[3]), split_pack2(v[4], v[5]), split_pack2(v[6], v[7])};
+  hi = __builtin_bit_cast(short8, uh);
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = v[j] - split_unpack((unsigned short)hi[j]);
+  const uint4v ul = {split_pack2(r[0], r[1]), split_pack2(r[2], r[3]), split_pack2(r[4], r[5]), split_pack2(r[6], r[7])};
+  lo = __builtin_bit_cast(short8, ul);
+}
+// acc += A B for operands given as (hi, lo) pairs of the split format: three MFMA passes, smallest terms first.
+__device__ __forceinline__ float4v mma_split3(const short8& ah, const short8& al, const short8& bh, const short8& bl, float4v acc) {
+  acc = split_mma(al, bh, acc);
+  acc = split_mma(ah, bl, acc);
+  return split_mma(ah, bh, acc);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

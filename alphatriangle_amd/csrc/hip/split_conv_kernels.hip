@@ -1,19 +1,21 @@
 // fp32-grade 3x3 convolutions for boards with W <= 15 and H <= 8 (the default 8x15 grid): fp32 activations in
-// memory, every GEMM as three bf16 MFMA passes over (hi, lo) operand splits with fp32 accumulation.
+// memory, every GEMM as three 16-bit MFMA passes over (hi, lo) operand splits with fp32 accumulation.
 //
 // The reference evaluates its network in fp32 (alphatriangle/nn/network.py:243-318, tests/nn/test_model.py:80-81);
-// gfx950's f32-input MFMA runs at 1/16 of the bf16 rate, so the reference-precision path of this engine writes each
-// fp32 operand as x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits) and computes
-//     W x  ~=  W_hi x_hi + W_lo x_hi + W_hi x_lo          (the dropped W_lo x_lo term is 2^-16 relative)
-// on the bf16 matrix cores: 3 MFMAs per product instead of 1, accumulators and everything element-wise in fp32.
-// Measured against an fp64 evaluation of the default network the logits are within 4 - 6e-6 (PyTorch's fp32 path:
-// 3 - 6e-7; a plain bf16 evaluation: ~1e-2) - see tests/test_gpu_nn_fp32.py.
+// gfx950's f32-input MFMA runs at 1/16 of the 16-bit rate, so the reference-precision path of this engine writes each
+// fp32 operand as x = hi + lo with hi = r16(x), lo = r16(x - hi) and computes
+//     W x  ~=  W_hi x_hi + W_lo x_hi + W_hi x_lo          (the dropped W_lo x_lo term is below the operands' own rounding)
+// on the 16-bit matrix cores: 3 MFMAs per product instead of 1, accumulators and everything element-wise in fp32.
+// r16 is fp16 (22 significant bits per operand) or bf16 (16 bits), fixed when the library is built (common.hpp).
+// Measured against an fp64 evaluation of the default network the logits are within 0.6 - 1.2e-6 with fp16 pairs and
+// 4 - 6e-6 with bf16 pairs (PyTorch's fp32 path: 0.5 - 2.3e-6; a plain bf16 evaluation: ~1e-2) - see
+// tests/test_gpu_nn_fp32.py.
 //
 // Layers served: the conv stem and both convolutions of every residual block
 // (alphatriangle/nn/model.py:20-37 conv_block, :40-59 ResidualBlock), BatchNorm folded.
 //
 // Structure (same halo-tile idea as conv_kernels.hip, re-balanced for a loop that is matrix-core bound):
-//   * one workgroup per sample; the sample sits in LDS as two bf16 planes (hi, lo) with a physical zero halo at a
+//   * one workgroup per sample; the sample sits in LDS as two 16-bit planes (hi, lo) with a physical zero halo at a
 //     16-pixel row pitch, so a 3x3 tap is a constant LDS offset and one fragment read of image row r serves the
 //     three vertical taps.  Only the 130 tile rows the main loop can touch are kept (37.4 KB per 128-channel
 //     plane): two planes are 75 KB, two workgroups per CU.
@@ -27,7 +29,7 @@ using namespace atrihip;
 
 struct SplitConvArgs {
   const float* in;         // [B, HW, Cin] f32
-  const unsigned short* w; // packed bf16 fragments, hi stream then lo stream (lo_off elements apart)
+  const unsigned short* w; // packed 16-bit fragments, hi stream then lo stream (lo_off elements apart)
   const float* bias;       // [>= Cout]
   const float* residual;   // [B, HW, Cout] f32 or nullptr (added before the activation)
   const float* post_add;   // [HW, Cout] f32 or nullptr (added after the activation)
@@ -118,9 +120,9 @@ __device__ __forceinline__ void split_mainloop(float4v (&acc)[8][2], const unsig
       if (t < T0 || t >= T0 + NT) continue;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[wc][dyi][n], ah, acc[t][n], 0, 0, 0);
-        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[wc][dyi][n], al, acc[t][n], 0, 0, 0);
-        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[wc][dyi][n], ah, acc[t][n], 0, 0, 0);
+        acc[t][n] = split_mma(wl[wc][dyi][n], ah, acc[t][n]);
+        acc[t][n] = split_mma(wh[wc][dyi][n], al, acc[t][n]);
+        acc[t][n] = split_mma(wh[wc][dyi][n], ah, acc[t][n]);
       }
     }
   }
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], first_act);
-        split_bf16x8(v, oh, ol);
+        split_op8(v, oh, ol);
       }
       *reinterpret_cast<short8*>(t1h + r * stride + cc * 16) = oh;
       *reinterpret_cast<short8*>(t1l + r * stride + cc * 16) = ol;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
         const int r = c / CPR, cc = c - r * CPR;
         const float f[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
         short8 oh, ol;
-        split_bf16x8(f, oh, ol);
+        split_op8(f, oh, ol);
         *reinterpret_cast<short8*>(t1h + r * stride + cc * 16) = oh;
         *reinterpret_cast<short8*>(t1l + r * stride + cc * 16) = ol;
       }
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void rowconv_split_kernel(SplitConvArgs a) 
           hi = act4s(hi, act);
           const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           short8 oh, ol;
-          split_bf16x8(f, oh, ol);
+          split_op8(f, oh, ol);
           const int off = (t * 16 + l15 + 1) * stride2 + cw * 64 + q4 * 16;
           *reinterpret_cast<short8*>(t2h + off) = oh;
           *reinterpret_cast<short8*>(t2l + off) = ol;
@@ -395,7 +397,7 @@ constexpr int kOutBytes = 128 * kOutPitch;
 extern "C" {
 
 // Residual block in one launch, fp32-grade: out = act(conv2(act(conv1(in))) + in) (+ post_add), 128 channels.
-// w1 / w2: packed bf16 fragments [hi stream | lo stream], lo1 / lo2 = element offset of the lo stream.
+// w1 / w2: packed 16-bit fragments [hi stream | lo stream], lo1 / lo2 = element offset of the lo stream.
 int atri_split_conv_pair(const float* in, const void* w1, long long lo1, const float* b1, const void* w2, long long lo2,
                          const float* b2, const float* post_add, float* out, int B, int H, int W, int C, int act,
                          hipStream_t stream) {

@@ -1,19 +1,19 @@
 // fp32-grade dense tail of the network: shared FC over the flattened body (split-K, final LayerNorm fused into the
 // staging), policy / value heads and the C51 expectation (alphatriangle/nn/model.py:232-266,
 // alphatriangle/nn/network.py:157-162).  Activations are fp32 in memory and in every element-wise step; each GEMM is
-// three bf16 MFMA passes over (hi, lo) operand splits (see split_conv_kernels.hip for the scheme).
+// three 16-bit MFMA passes over (hi, lo) operand splits (see split_conv_kernels.hip for the scheme).
 #include "common.hpp"
 
 using namespace atrihip;
 
 namespace {
-constexpr int kPitch = 288;  // bytes per 128-wide bf16 LDS row (256 + 32): 16-byte fragment reads of 16 rows x 4 column groups hit distinct banks
+constexpr int kPitch = 288;  // bytes per 128-wide 16-bit LDS row (256 + 32): 16-byte fragment reads of 16 rows x 4 column groups hit distinct banks
 }
 
 // Shared FC fed directly by the body's [B][HW][128] fp32 rows, 64 samples x one K split per workgroup.  The final
 // LayerNorm - when there is one - is applied in fp32 to each 128-wide pixel row while it is staged (16 lanes per row;
 // LN = 1: normalisation only, the affine part folded into the weights by the host; LN = 2: with the affine part),
-// the row is then split into the two bf16 planes; the "other" features are read from the caller's f32 rows as the last
+// the row is then split into the two 16-bit planes; the "other" features are read from the caller's f32 rows as the last
 // K steps.  steps_per_split is a multiple of 4, so every staged chunk of 4 K-steps is exactly one pixel row.
 //
 // The workgroup is specialised: waves 4-7 are producers (global rows -> LayerNorm -> split -> LDS tile), waves 0-3 are
@@ -90,11 +90,11 @@ __global__ __launch_bounds__(512, 1) void fc_rows_split_kernel(const float* __re
     auto put = [&](const float (&f)[8], int i, int buf) {
       const int c = pt + i * 256, r = c >> 4, cc = c & 15;
       short8 xh, xl;
-      split_bf16x8(f, xh, xl);
+      split_op8(f, xh, xl);
       *reinterpret_cast<short8*>(xs[buf][0] + r * kPitch + cc * 16) = xh;
       *reinterpret_cast<short8*>(xs[buf][1] + r * kPitch + cc * 16) = xl;
     };
-    // registers -> (LayerNorm) -> the two bf16 planes of tile buffer `buf`
+    // registers -> (LayerNorm) -> the two 16-bit planes of tile buffer `buf`
     auto stage = [&](const float4 (&v)[MT][2], int buf) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(512, 1) void fc_rows_split_kernel(const float* __re
       for (int t = 0; t < MT; ++t) {
         const short8 xh = *reinterpret_cast<const short8*>(xh_base + t * 16 * kPitch + ks * 64);
         const short8 xl = *reinterpret_cast<const short8*>(xl_base + t * 16 * kPitch + ks * 64);
-        acc[t][0] = mfma_split(wh[ks][0], wl[ks][0], xh, xl, acc[t][0]);
-        acc[t][1] = mfma_split(wh[ks][1], wl[ks][1], xh, xl, acc[t][1]);
+        acc[t][0] = mma_split3(wh[ks][0], wl[ks][0], xh, xl, acc[t][0]);
+        acc[t][1] = mma_split3(wh[ks][1], wl[ks][1], xh, xl, acc[t][1]);
       }
       load_wslice(s0 + 4, ks);  // the slice just used takes the next chunk's weights
     }
@@ -277,8 +277,8 @@ __device__ __forceinline__ void gemm128_split(const unsigned short* __restrict__
   for (int kc = 0; kc < 4; ++kc) {
     const short8 xh = *reinterpret_cast<const short8*>(tile_h + kc * 64);
     const short8 xl = *reinterpret_cast<const short8*>(tile_l + kc * 64);
-    acc[0] = mfma_split(wh[kc][0], wl[kc][0], xh, xl, acc[0]);
-    acc[1] = mfma_split(wh[kc][1], wl[kc][1], xh, xl, acc[1]);
+    acc[0] = mma_split3(wh[kc][0], wl[kc][0], xh, xl, acc[0]);
+    acc[1] = mma_split3(wh[kc][1], wl[kc][1], xh, xl, acc[1]);
   }
 }
 }  // namespace
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
       }
     }
     short8 xh, xl;
-    split_bf16x8(v, xh, xl);
+    split_op8(v, xh, xl);
     *reinterpret_cast<short8*>(s_tile[0] + r * kHeadPitchS + n0 * 2) = xh;
     *reinterpret_cast<short8*>(s_tile[1] + r * kHeadPitchS + n0 * 2) = xl;
   }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
     hi = act4h(hi, a.act);
     const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     short8 xh, xl;
-    split_bf16x8(f, xh, xl);
+    split_op8(f, xh, xl);
     unsigned char* dh = (head == 0 ? p_tile[0] : v_tile[0]) + l15 * kHeadPitchS + ch * 2;
     unsigned char* dl = (head == 0 ? p_tile[1] : v_tile[1]) + l15 * kHeadPitchS + ch * 2;
     *reinterpret_cast<short8*>(dh) = xh;
@@ -411,6 +411,10 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
 }
 
 extern "C" {
+
+// Operand format the split kernels of this library were built for: 0 = bf16 (hi, lo) pairs, 1 = fp16 pairs.  The host
+// packs weight fragments accordingly.
+int atri_split_operand_format() { return kSplitF16 ? 1 : 0; }
 
 // max_splits > SK: slabs must hold max_splits x B x 128 floats; the split count then follows the live row count (fc_plan)
 // and atri_split_heads_dyn has to be given the same numbers.

@@ -1,6 +1,6 @@
 // fp32-grade 3x3 convolutions for boards that do not fit the 8x15 halo tile of split_conv_kernels.hip (the 12x21 grid of
 // the large preset; any board with 16 * ceil(H * (W + 1) / 16) + 2 * W + 4 <= 320 flat rows): fp32 activations in memory,
-// every GEMM as three bf16 MFMA passes over (hi, lo) operand splits with fp32 accumulation (the scheme of
+// every GEMM as three 16-bit MFMA passes over (hi, lo) operand splits with fp32 accumulation (the scheme of
 // split_conv_kernels.hip), on the flat-tile geometry of flatconv_kernels.hip.
 //
 // Layers served: the conv stem and both convolutions of every residual block
@@ -32,7 +32,7 @@ using namespace atrihip;
 
 struct SplitFlatArgs {
   const float* in;          // [B, HW, 128] f32 (residual block)
-  const unsigned short* w;  // first convolution: packed bf16 fragments, hi stream then lo stream (lo_off elements apart)
+  const unsigned short* w;  // first convolution: packed 16-bit fragments, hi stream then lo stream (lo_off elements apart)
   const float* bias;
   const unsigned short* w2; // second convolution
   const float* bias2;
@@ -119,11 +119,11 @@ __device__ __forceinline__ void sf_mainloop(float4v (&acc)[TPW][2 * CB], const u
         const short8 yh = *reinterpret_cast<const short8*>(py), yl = *reinterpret_cast<const short8*>(py + R::kLo);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < NF; ++k) acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[k], xh, acc[t][k], 0, 0, 0);
+        for (int k = 0; k < NF; ++k) acc[t][k] = split_mma(wl[k], xh, acc[t][k]);
 #pragma unroll
-        for (int k = 0; k < NF; ++k) acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[k], xl, acc[t][k], 0, 0, 0);
+        for (int k = 0; k < NF; ++k) acc[t][k] = split_mma(wh[k], xl, acc[t][k]);
 #pragma unroll
-        for (int k = 0; k < NF; ++k) acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[k], xh, acc[t][k], 0, 0, 0);
+        for (int k = 0; k < NF; ++k) acc[t][k] = split_mma(wh[k], xh, acc[t][k]);
         xh = yh;
         xl = yl;
       }
@@ -180,7 +180,7 @@ __device__ __forceinline__ void sf_convs(const SplitFlatArgs& a, unsigned char* 
         }
         act8<RELU>(v, act);
         short8 oh = (short8){0, 0, 0, 0, 0, 0, 0, 0}, ol = oh;
-        if (pixel) split_bf16x8(v, oh, ol);
+        if (pixel) split_op8(v, oh, ol);
         unsigned char* p = tile2 + R2::off(f + P + 1, (h * CB1 + ws) * 4 + q4);
         *reinterpret_cast<short8*>(p) = oh;
         *reinterpret_cast<short8*>(p + R2::kLo) = ol;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kSfThreads, 2) void flatconv_split_kernel(SplitFlat
           v[4] += gv * w1.x; v[5] += gv * w1.y; v[6] += gv * w1.z; v[7] += gv * w1.w;
         }
         act8<RELU>(v, act);
-        split_bf16x8(v, oh, ol);
+        split_op8(v, oh, ol);
       }
       unsigned char* p = smem + R1::off(r, cc);
       *reinterpret_cast<short8*>(p) = oh;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kSfThreads, 2) void flatconv_split_kernel(SplitFlat
         const int y = (pp * a.wmagic) >> 16, x = pp - y * W;
         const float f[8] = {xin[i][0].x, xin[i][0].y, xin[i][0].z, xin[i][0].w, xin[i][1].x, xin[i][1].y, xin[i][1].z, xin[i][1].w};
         short8 oh, ol;
-        split_bf16x8(f, oh, ol);
+        split_op8(f, oh, ol);
         unsigned char* p = smem + R1::off(y * P + x + P + 1, cc);
         *reinterpret_cast<short8*>(p) = oh;
         *reinterpret_cast<short8*>(p + R1::kLo) = ol;
@@ -467,7 +467,7 @@ int atri_split_flatconv_supported(int H, int W) {
 }
 
 // Residual block in one launch, fp32-grade: out = act(conv2(act(conv1(in))) + in) (+ post_add), 128 channels.
-// w1 / w2: packed bf16 fragments [hi stream | lo stream], lo1 / lo2 = element offset of the lo stream.
+// w1 / w2: packed 16-bit fragments [hi stream | lo stream], lo1 / lo2 = element offset of the lo stream.
 int atri_split_flatconv_pair(const float* in, const void* w1, long long lo1, const float* b1, const void* w2, long long lo2,
                              const float* b2, const float* post_add, float* out, int B, int H, int W, int C, int act,
                              hipStream_t stream) {

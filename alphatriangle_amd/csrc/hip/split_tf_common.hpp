@@ -1,5 +1,5 @@
 // Helpers shared by the fp32-grade Transformer kernels (split_tf_kernels.hip: one workgroup per sample, up to 128
-// tokens; split_tf_rows_kernels.hip: 129..256 tokens): (hi, lo) bf16 planes of a 128-row token tile in LDS, a
+// tokens; split_tf_rows_kernels.hip: 129..256 tokens): (hi, lo) 16-bit planes of a 128-row token tile in LDS, a
 // 64-register ring of packed weight fragments, the K = 128 GEMM step over them, LayerNorm of rows on their way from
 // memory into the planes.
 #pragma once
@@ -8,7 +8,7 @@
 namespace atrihip {
 namespace splittf {
 constexpr int kDs = 128;
-constexpr int kStrideS = 288;                  // bytes per token row of a bf16 plane
+constexpr int kStrideS = 288;                  // bytes per token row of a 16-bit plane
 constexpr int kPlane = 128 * kStrideS;         // 36,864
 constexpr int kRegion = 2 * kPlane;            // 73,728
 
@@ -62,11 +62,11 @@ __device__ __forceinline__ void gemm_split_k128(float4v (&acc)[4][2], WSplit& w,
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (SWAP) {
-        acc[t][0] = mfma_split(xh[kc & 1][t], xl[kc & 1][t], w.h[kc][0], w.l[kc][0], acc[t][0]);
-        acc[t][1] = mfma_split(xh[kc & 1][t], xl[kc & 1][t], w.h[kc][1], w.l[kc][1], acc[t][1]);
+        acc[t][0] = mma_split3(xh[kc & 1][t], xl[kc & 1][t], w.h[kc][0], w.l[kc][0], acc[t][0]);
+        acc[t][1] = mma_split3(xh[kc & 1][t], xl[kc & 1][t], w.h[kc][1], w.l[kc][1], acc[t][1]);
       } else {
-        acc[t][0] = mfma_split(w.h[kc][0], w.l[kc][0], xh[kc & 1][t], xl[kc & 1][t], acc[t][0]);
-        acc[t][1] = mfma_split(w.h[kc][1], w.l[kc][1], xh[kc & 1][t], xl[kc & 1][t], acc[t][1]);
+        acc[t][0] = mma_split3(w.h[kc][0], w.l[kc][0], xh[kc & 1][t], xl[kc & 1][t], acc[t][0]);
+        acc[t][1] = mma_split3(w.h[kc][1], w.l[kc][1], xh[kc & 1][t], xl[kc & 1][t], acc[t][1]);
       }
     }
     if (NEXT) load_wslice(w, kc, next);
@@ -76,7 +76,7 @@ __device__ __forceinline__ void gemm_split_k128(float4v (&acc)[4][2], WSplit& w,
 
 __device__ __forceinline__ void split8(const float4v& a, const float4v& b, short8& hi, short8& lo) {
   const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  split_bf16x8(f, hi, lo);
+  split_op8(f, hi, lo);
 }
 
 // LayerNorm (no affine part) of a sample's rows from fp32 global memory in two steps, 8 lanes per row and two rows per
@@ -131,12 +131,12 @@ __device__ __forceinline__ void ln_finish(LnRows& x, unsigned char* dst, float e
     for (int j = 0; j < 4; ++j) {
       const float4& q = x.v[pass][j];
       const float o0 = q.x * rstd, o1 = q.y * rstd, o2 = q.z * rstd, o3 = q.w * rstd;
-      const unsigned h0 = pack_bf16x2(o0, o1), h1 = pack_bf16x2(o2, o3);
-      const float r0 = o0 - bf16_to_float((unsigned short)(h0 & 0xFFFF)), r1 = o1 - bf16_to_float((unsigned short)(h0 >> 16));
-      const float r2 = o2 - bf16_to_float((unsigned short)(h1 & 0xFFFF)), r3 = o3 - bf16_to_float((unsigned short)(h1 >> 16));
+      const unsigned h0 = split_pack2(o0, o1), h1 = split_pack2(o2, o3);
+      const float r0 = o0 - split_unpack((unsigned short)(h0 & 0xFFFF)), r1 = o1 - split_unpack((unsigned short)(h0 >> 16));
+      const float r2 = o2 - split_unpack((unsigned short)(h1 & 0xFFFF)), r3 = o3 - split_unpack((unsigned short)(h1 >> 16));
       unsigned char* p = dst + row * kStrideS + (j * 8 + l8) * 8;
       *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(p + kPlane) = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+      *reinterpret_cast<uint2*>(p + kPlane) = make_uint2(split_pack2(r0, r1), split_pack2(r2, r3));
     }
   }
 }

@@ -3,7 +3,7 @@
 // alphatriangle/nn/model.py:189-196, LayerNorm affine parts folded into the following projections by the host.
 //
 // Precision scheme as in split_conv_kernels.hip: fp32 activations in memory and in every element-wise step
-// (LayerNorm statistics, softmax, residual adds), each matrix product as three bf16 MFMA passes over (hi, lo)
+// (LayerNorm statistics, softmax, residual adds), each matrix product as three 16-bit MFMA passes over (hi, lo)
 // operand splits with fp32 accumulation.
 //
 // Work split: wave w = (channel block / head h = w & 3, token half = w >> 2); every GEMM gives a wave 64 tokens x
@@ -71,7 +71,7 @@ __device__ __forceinline__ void attn_scores(float4v (&st)[8], const short8* kimg
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt) {
     const short8 kh = kimg[(size_t)kt * 128], kl = kimg[(size_t)kt * 128 + 64];
-    st[kt] = mfma_split(kh, kl, qh, ql, (float4v){0.f, 0.f, 0.f, 0.f});
+    st[kt] = mma_split3(kh, kl, qh, ql, (float4v){0.f, 0.f, 0.f, 0.f});
   }
 #pragma unroll
   for (int kt = TAIL ? 7 : 0; kt < 8; ++kt)
@@ -123,8 +123,8 @@ __device__ __forceinline__ bool attention_tiles(const short8 (&qh)[4], const sho
     for (int kb = 0; kb < 4; ++kb) {
       short8 ph, pl;
       split8(s[2 * kb], s[2 * kb + 1], ph, pl);
-      o0 = mfma_split(vth[kb][0], vtl[kb][0], ph, pl, o0);
-      o1 = mfma_split(vth[kb][1], vtl[kb][1], ph, pl, o1);
+      o0 = mma_split3(vth[kb][0], vtl[kb][0], ph, pl, o0);
+      o1 = mma_split3(vth[kb][1], vtl[kb][1], ph, pl, o1);
     }
     const float inv = 1.0f / sum;
 #pragma unroll
@@ -267,13 +267,24 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   {
     const short8* kimg = reinterpret_cast<const short8*>(Bq) + (size_t)(cb * 8) * 2 * 64 + lane;
     const WRef wo = wref(a.wo, a.lo_o, frag);
-    bool suspect;
-    if (HW > 112) {
-      suspect = attention_tiles<false, true>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
+    if constexpr (kSplitF16) {
+      // fp16 operands: the probabilities have to stay within fp16's range, so the row maximum is always subtracted
+      if (HW > 112) {
+        (void)attention_tiles<true, true>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
+      } else {
+        (void)attention_tiles<true, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
+      }
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) load_wslice(w, kc, wo);  // the max-free pass starts these loads itself
     } else {
-      suspect = attention_tiles<false, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
+      bool suspect;
+      if (HW > 112) {
+        suspect = attention_tiles<false, true>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
+      } else {
+        suspect = attention_tiles<false, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
+      }
+      if (__builtin_amdgcn_ballot_w64(suspect) != 0) (void)attention_tiles<true, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
     }
-    if (__builtin_amdgcn_ballot_w64(suspect) != 0) (void)attention_tiles<true, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
   }
   ATRI_PHASE(6);
   __syncthreads();  // attention output complete; the K image in region B is dead

@@ -4,7 +4,7 @@
 // reference evaluates the layer in fp32 on any grid (alphatriangle/nn/model.py:283-289, tests/nn/test_model.py:80-81).
 //
 // Precision scheme as in split_conv_kernels.hip: fp32 activations in memory and in every element-wise step (LayerNorm
-// statistics, softmax, residual adds), each matrix product as three bf16 MFMA passes over (hi, lo) operand splits
+// statistics, softmax, residual adds), each matrix product as three 16-bit MFMA passes over (hi, lo) operand splits
 // with fp32 accumulation.
 //
 //   qkv_attn_split_kernel      LayerNorm1 + QKV projection + attention; Q, K and V never go to memory.  Persistent
@@ -88,11 +88,11 @@ __device__ __forceinline__ void qa_gemm(float4v (&acc)[2][2], const short8* wlan
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (SWAP) {
-        acc[t][0] = mfma_split(xh[t][kc], xl[t][kc], wh0, wl0, acc[t][0]);
-        acc[t][1] = mfma_split(xh[t][kc], xl[t][kc], wh1, wl1, acc[t][1]);
+        acc[t][0] = mma_split3(xh[t][kc], xl[t][kc], wh0, wl0, acc[t][0]);
+        acc[t][1] = mma_split3(xh[t][kc], xl[t][kc], wh1, wl1, acc[t][1]);
       } else {
-        acc[t][0] = mfma_split(wh0, wl0, xh[t][kc], xl[t][kc], acc[t][0]);
-        acc[t][1] = mfma_split(wh1, wl1, xh[t][kc], xl[t][kc], acc[t][1]);
+        acc[t][0] = mma_split3(wh0, wl0, xh[t][kc], xl[t][kc], acc[t][0]);
+        acc[t][1] = mma_split3(wh1, wl1, xh[t][kc], xl[t][kc], acc[t][1]);
       }
     }
   }
@@ -117,7 +117,7 @@ __device__ __forceinline__ bool qa_tiles(const short8* kimg, const short8* vimg,
 #pragma unroll
     for (int kt = 0; kt < 16; ++kt) {
       const short8 kh = kimg[(kt * 2) * 64], kl = kimg[(kt * 2 + 1) * 64];
-      st[kt] = mfma_split(kh, kl, Qh[t], Ql[t], (float4v){0.f, 0.f, 0.f, 0.f});
+      st[kt] = mma_split3(kh, kl, Qh[t], Ql[t], (float4v){0.f, 0.f, 0.f, 0.f});
       if (kt >= kt_full) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -146,8 +146,8 @@ __device__ __forceinline__ bool qa_tiles(const short8* kimg, const short8* vimg,
       short8 ph, pl;
       split8(st[2 * kb], st[2 * kb + 1], ph, pl);
       const short8* vb = vimg + (size_t)(kb * 4) * 64;
-      o0 = mfma_split(vb[0], vb[64], ph, pl, o0);
-      o1 = mfma_split(vb[128], vb[192], ph, pl, o1);
+      o0 = mma_split3(vb[0], vb[64], ph, pl, o0);
+      o1 = mma_split3(vb[128], vb[192], ph, pl, o1);
     }
     const float inv = 1.0f / sum;
     // lane holds dims q4 * 8 .. + 7 of query q0 + l15
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_split_kernel(SplitQkvAttnArgs
         for (int kc = 0; kc < 4; ++kc) {
           const float4 q0 = xr[t][kc][0], q1 = xr[t][kc][1];
           const float f[8] = {q0.x * rstd, q0.y * rstd, q0.z * rstd, q0.w * rstd, q1.x * rstd, q1.y * rstd, q1.z * rstd, q1.w * rstd};
-          split_bf16x8(f, xh[t][kc], xl[t][kc]);
+          split_op8(f, xh[t][kc], xl[t][kc]);
         }
       }
     }
@@ -297,8 +297,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_split_kernel(SplitQkvAttnArgs
       // Softmax is shift invariant and the (hi, lo) split keeps fp32's exponent range, so the fast pass skips the row
       // maximum and checks the denominators instead: a wave that saw one outside [2^-100, 2^100] (overflow, total
       // underflow, NaN) repeats its tiles with the maximum subtracted and overwrites its outputs.
-      const bool suspect = qa_tiles<KTF, false>(kimg, vimg, Qh, Ql, og, HW, oct, q4, l15);
-      if (__builtin_amdgcn_ballot_w64(suspect) != 0) (void)qa_tiles<KTF, true>(kimg, vimg, Qh, Ql, og, HW, oct, q4, l15);
+      if constexpr (kSplitF16) {  // fp16 operands: probabilities must stay within fp16's range, always subtract the maximum
+        (void)qa_tiles<KTF, true>(kimg, vimg, Qh, Ql, og, HW, oct, q4, l15);
+      } else {
+        const bool suspect = qa_tiles<KTF, false>(kimg, vimg, Qh, Ql, og, HW, oct, q4, l15);
+        if (__builtin_amdgcn_ballot_w64(suspect) != 0) (void)qa_tiles<KTF, true>(kimg, vimg, Qh, Ql, og, HW, oct, q4, l15);
+      }
       asm volatile("" ::"v"(touch));  // keeps the touch loads alive
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // every wave is done with the images; the next head's weights are in LDS

@@ -165,8 +165,16 @@ def _pack_index(taps: int, cin: int, cout: int, device: torch.device) -> tuple[t
     return flat, nb_n
 
 
-def pack_gemm_weights(w: torch.Tensor, device: torch.device) -> tuple[torch.Tensor, int]:
-    """``w[taps, Cin, Cout]`` (f32) -> bf16 fragments ``[NB][taps*KC][wave 4][n 2][lane 64][8]`` (+1 spare step).
+def split_operand_dtype() -> torch.dtype:
+    """16-bit format of the (hi, lo) operand pairs the loaded kernel library was built for (csrc/hip/common.hpp)."""
+    try:
+        return torch.float16 if int(hb.lib().atri_split_operand_format()) == 1 else torch.bfloat16
+    except Exception:  # noqa: BLE001 - no kernel library on this host
+        return torch.bfloat16
+
+
+def pack_gemm_weights(w: torch.Tensor, device: torch.device, dtype: torch.dtype = torch.bfloat16) -> tuple[torch.Tensor, int]:
+    """``w[taps, Cin, Cout]`` (f32) -> 16-bit fragments ``[NB][taps*KC][wave 4][n 2][lane 64][8]`` (+1 spare step).
 
     Fragment element ``j`` of lane ``l`` is ``W[k = kc*32 + 8*(l>>4) + j][cout]`` with
     ``cout = nb*128 + wave*32 + (r>>2)*8 + n*4 + (r&3)``, ``r = l & 15``: after the MFMA
@@ -177,20 +185,22 @@ def pack_gemm_weights(w: torch.Tensor, device: torch.device) -> tuple[torch.Tens
     wpad = torch.zeros(taps, cin, nb_n * 128, dtype=torch.float32, device=device)
     wpad[:, :, :cout] = w.detach().to(device=device, dtype=torch.float32)
     packed = wpad.reshape(-1)[flat]
-    out = torch.cat([packed, torch.zeros(4 * 2 * 64 * 8, dtype=torch.float32, device=device)]).to(torch.bfloat16)
+    out = torch.cat([packed, torch.zeros(4 * 2 * 64 * 8, dtype=torch.float32, device=device)]).to(dtype)
     return out, nb_n
 
 
 def pack_gemm_weights_split(w: torch.Tensor, device: torch.device) -> tuple[torch.Tensor, int, int]:
-    """fp32 weights as two packed bf16 fragment streams, ``hi = bf16(w)`` and ``lo = bf16(w - hi)``, concatenated.
+    """fp32 weights as two packed 16-bit fragment streams, ``hi = r16(w)`` and ``lo = r16(w - hi)``, concatenated
+    (``r16`` = rounding to the library's split operand format, bf16 or fp16).
 
     Returns ``(packed, n_blocks, lo_offset_in_elements)``; both streams use the layout of :func:`pack_gemm_weights`.
     """
+    dt = split_operand_dtype()
     w32 = w.detach().to(device=device, dtype=torch.float32)
-    hi = w32.to(torch.bfloat16)
+    hi = w32.to(dt)
     lo = w32 - hi.float()
-    p_hi, nb = pack_gemm_weights(hi.float(), device)
-    p_lo, _ = pack_gemm_weights(lo, device)
+    p_hi, nb = pack_gemm_weights(hi.float(), device, dt)
+    p_lo, _ = pack_gemm_weights(lo, device, dt)
     return torch.cat([p_hi, p_lo]), nb, int(p_hi.numel())
 
 

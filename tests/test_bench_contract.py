@@ -83,5 +83,5 @@ def test_bench_line_names_its_precision_scheme():
     res = _run(["--steps", "1", "--warmup", "1", "--games", "256", "--sims", "8", "--train-steps", "1"])
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
-    assert out["dtype"] == "fp32" and out["dtype_detail"].startswith("bf16x3") and "16-bit operands" in out["dtype_detail"]
+    assert out["dtype"] == "fp32" and out["dtype_detail"].startswith("fp16x3") and "22-bit operands" in out["dtype_detail"]
     assert out["backend"] == "none" and out["ranks_seen"] == 1
