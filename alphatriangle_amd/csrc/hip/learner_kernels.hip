@@ -182,6 +182,73 @@ __global__ void per_update_paths_kernel(double* tree, long long P, int levels, c
   }
 }
 
+// The same recomputation spread over the chip for trees of more than kPerTopLevels levels.  The tree is cut kPerTopLevels
+// below the root: each of the 2^kPerTopLevels subtrees is walked by one workgroup, which first collects the touched leaves
+// that fall into its subtree (a compaction through an LDS counter; a list that overflows falls back to re-scanning all
+// indices per level) and then recomputes their ancestors level by level up to the subtree's root, with workgroup
+// barriers only - no subtree depends on another one.  per_update_top_kernel then rebuilds the 2^kPerTopLevels - 1 nodes
+// above the cut in one small workgroup.  No atomics on global memory, no flags between workgroups.
+constexpr int kPerTopLevels = 8;
+constexpr int kPerListCap = 8192;
+
+__global__ __launch_bounds__(256) void per_update_subtrees_kernel(double* tree, long long P, int sub_levels, const int* idx,
+                                                                  const int* count_ptr, int count_max) {
+  __shared__ int list[kPerListCap];
+  __shared__ int cnt;
+  const int n = count_ptr ? min(*count_ptr, count_max) : count_max;
+  const int tid = threadIdx.x;
+  for (int sub = blockIdx.x; sub < (1 << kPerTopLevels); sub += gridDim.x) {
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+      const int leaf = idx[i];
+      if ((leaf >> sub_levels) == sub) {
+        const int k = atomicAdd(&cnt, 1);
+        if (k < kPerListCap) list[k] = leaf;
+      }
+    }
+    __syncthreads();
+    const int m = cnt;
+    if (m == 0) continue;  // workgroup-uniform
+    if (m <= kPerListCap) {
+      for (int l = 1; l <= sub_levels; ++l) {
+        const int level_nodes = 1 << (sub_levels - l);  // nodes of this subtree at this level
+        if (m >= level_nodes) {
+          // more touched leaves than nodes: recompute the whole level of the subtree (each node once)
+          const long long first = ((P >> l) + ((long long)sub << (sub_levels - l)));
+          for (int j = tid; j < level_nodes; j += blockDim.x) {
+            const long long node = first + j;
+            tree[node] = tree[2 * node] + tree[2 * node + 1];
+          }
+        } else {
+          for (int j = tid; j < m; j += blockDim.x) {
+            const long long node = (P + list[j]) >> l;
+            tree[node] = tree[2 * node] + tree[2 * node + 1];
+          }
+        }
+        __syncthreads();
+      }
+    } else {
+      for (int l = 1; l <= sub_levels; ++l) {
+        for (int i = tid; i < n; i += blockDim.x) {
+          const int leaf = idx[i];
+          if ((leaf >> sub_levels) != sub) continue;
+          const long long node = (P + leaf) >> l;
+          tree[node] = tree[2 * node] + tree[2 * node + 1];
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void per_update_top_kernel(double* tree) {
+  for (int level = 1 << (kPerTopLevels - 1); level >= 1; level >>= 1) {
+    for (int i = level + threadIdx.x; i < 2 * level; i += blockDim.x) tree[i] = tree[2 * i] + tree[2 * i + 1];
+    __syncthreads();
+  }
+}
+
 __global__ void per_rebuild_kernel(double* tree, long long P) {
   for (long long level = P >> 1; level >= 1; level >>= 1) {
     for (long long i = level + threadIdx.x; i < 2 * level; i += blockDim.x) tree[i] = tree[2 * i] + tree[2 * i + 1];
@@ -223,6 +290,48 @@ __global__ void per_sample_kernel(const double* tree, long long P, int size, int
   float gm = 0.f;
   for (int k = 0; k < (blockDim.x >> 6); ++k) gm = fmaxf(gm, red[k]);
   if (i < B) out_w[i] = gm > 1e-9f ? wgt / gm : 1.0f;
+}
+
+// The same for batches above one workgroup: 256 samples per workgroup, raw weights and one maximum per workgroup first,
+// the normalisation by the batch maximum in a second launch (per_sample_norm_kernel).
+__global__ __launch_bounds__(256) void per_sample_multi_kernel(const double* tree, long long P, int size, int B, const float* rnd,
+                                                               float beta, int* out_idx, float* out_w, float* wg_max) {
+  __shared__ float red[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float wgt = 0.f;
+  if (i < B) {
+    const double total = tree[1];
+    const double seg = total / (double)B;
+    double value = ((double)i + (double)rnd[i]) * seg;
+    long long node = 1;
+    while (node < P) {
+      const double left = tree[2 * node];
+      if (value <= left) {
+        node = 2 * node;
+      } else {
+        value -= left;
+        node = 2 * node + 1;
+      }
+    }
+    int leaf = (int)(node - P);
+    if (leaf >= size) leaf = size - 1;  // rounding at the upper edge of the mass
+    const double pr = tree[P + leaf];
+    const double prob = total > 0.0 ? pr / total : 0.0;
+    wgt = prob > 1e-9 ? (float)pow((double)size * prob, -(double)beta) : 0.f;
+    out_idx[i] = leaf;
+    out_w[i] = wgt;
+  }
+  const float mx = wave_max(wgt);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) wg_max[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void per_sample_norm_kernel(float* out_w, int B, const float* wg_max, int n_wg) {
+  float gm = 0.f;
+  for (int k = 0; k < n_wg; ++k) gm = fmaxf(gm, wg_max[k]);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B) out_w[i] = gm > 1e-9f ? out_w[i] / gm : 1.0f;
 }
 
 // priority = (|err| + eps)^alpha, written to the leaves; tracks the running maximum.
@@ -591,7 +700,14 @@ int atri_per_update_paths(double* tree, long long P, const int* idx, const int* 
   if (count_max <= 0) return 0;
   int levels = 0;
   while ((1LL << levels) < P) ++levels;
-  hipLaunchKernelGGL(per_update_paths_kernel, dim3(1), dim3(1024), 0, s, tree, P, levels, idx, count_ptr, count_max);
+  if (levels <= kPerTopLevels + 2 || count_max <= 256) {
+    // small trees, or so few leaves that one workgroup walks them faster than 256 workgroups scan for them
+    hipLaunchKernelGGL(per_update_paths_kernel, dim3(1), dim3(1024), 0, s, tree, P, levels, idx, count_ptr, count_max);
+    return (int)hipGetLastError();
+  }
+  hipLaunchKernelGGL(per_update_subtrees_kernel, dim3(1 << kPerTopLevels), dim3(256), 0, s, tree, P, levels - kPerTopLevels, idx,
+                     count_ptr, count_max);
+  hipLaunchKernelGGL(per_update_top_kernel, dim3(1), dim3(256), 0, s, tree);
   return (int)hipGetLastError();
 }
 int atri_per_rebuild(double* tree, long long P, hipStream_t s) {
@@ -603,6 +719,15 @@ int atri_per_sample(const double* tree, long long P, int size, int B, const floa
   if (B <= 0 || B > 1024 || size <= 0) return -10;
   int threads = ((B + 63) / 64) * 64;
   hipLaunchKernelGGL(per_sample_kernel, dim3(1), dim3(threads), 0, s, tree, P, size, B, rnd, beta, out_idx, out_w);
+  return (int)hipGetLastError();
+}
+// Batches of any size: wg_max is scratch of ceil(B / 256) floats.
+int atri_per_sample_large(const double* tree, long long P, int size, int B, const float* rnd, float beta, int* out_idx,
+                          float* out_w, float* wg_max, hipStream_t s) {
+  if (B <= 0 || size <= 0 || wg_max == nullptr) return -10;
+  const int nb = (B + 255) / 256;
+  hipLaunchKernelGGL(per_sample_multi_kernel, dim3(nb), dim3(256), 0, s, tree, P, size, B, rnd, beta, out_idx, out_w, wg_max);
+  hipLaunchKernelGGL(per_sample_norm_kernel, dim3(nb), dim3(256), 0, s, out_w, B, wg_max, nb);
   return (int)hipGetLastError();
 }
 int atri_per_priorities(double* tree, long long P, const int* idx, const float* err, int n, float alpha, float eps,

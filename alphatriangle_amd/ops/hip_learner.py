@@ -208,7 +208,12 @@ def per_rebuild(tree: torch.Tensor, P: int) -> None:
 
 
 def per_sample(tree: torch.Tensor, P: int, size: int, batch: int, rnd: torch.Tensor, beta: float, out_idx: torch.Tensor, out_w: torch.Tensor) -> None:
-    hb.call("atri_per_sample", hb.ptr(tree), hb.i64(P), hb.i32(size), hb.i32(batch), hb.ptr(rnd), hb.f32(beta), hb.ptr(out_idx), hb.ptr(out_w))
+    if batch <= 1024:  # one workgroup, one launch
+        hb.call("atri_per_sample", hb.ptr(tree), hb.i64(P), hb.i32(size), hb.i32(batch), hb.ptr(rnd), hb.f32(beta), hb.ptr(out_idx), hb.ptr(out_w))
+        return
+    scratch = torch.empty((batch + 255) // 256, dtype=torch.float32, device=tree.device)
+    hb.call("atri_per_sample_large", hb.ptr(tree), hb.i64(P), hb.i32(size), hb.i32(batch), hb.ptr(rnd), hb.f32(beta), hb.ptr(out_idx),
+            hb.ptr(out_w), hb.ptr(scratch))
 
 
 def per_priorities(tree: torch.Tensor, P: int, idx: torch.Tensor, err: torch.Tensor, alpha: float, eps: float, max_prio: torch.Tensor) -> None:

@@ -158,8 +158,6 @@ class DeviceReplayBuffer:
             if current_train_step is None:
                 raise ValueError("current_train_step is required for PER sampling.")
             assert self.tree is not None
-            if batch_size > 1024:
-                raise ValueError("PER batch size above 1024 is not supported by the sampling kernel")
             rnd = torch.rand(batch_size, device=dev, generator=self._gen)
             idx = torch.empty(batch_size, dtype=torch.int32, device=dev)
             w = torch.empty(batch_size, dtype=torch.float32, device=dev)

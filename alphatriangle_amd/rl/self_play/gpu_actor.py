@@ -60,6 +60,8 @@ class GpuMoveReport:
     per_game: dict[str, np.ndarray] = field(default_factory=dict)
     # leaf slots of this move by kind; ``expand`` slots are the ones that needed a network evaluation
     slot_census: dict[str, int] = field(default_factory=dict)
+    # GPU time of the move's phases in milliseconds (HIP events; only with --profile, see gpu_profile.py)
+    phase_ms: dict[str, float] = field(default_factory=dict)
 
 
 class LeafEvaluator:
@@ -175,6 +177,8 @@ class GpuSelfPlayActor:
         device: torch.device,
         seed: int = 0,
         evaluator: LeafEvaluator | None = None,
+        profile_dir: str | None = None,
+        rank: int = 0,
     ):
         self.env_config = env_config
         self.mcts_config = mcts_config
@@ -214,6 +218,12 @@ class GpuSelfPlayActor:
         self._graph: torch.cuda.CUDAGraph | None = None
         self._t0 = time.perf_counter()
         self.profile_ranges = bool(train_config.PROFILE_WORKERS)  # --profile: roctx ranges around the move phases
+        # --profile also times the phases with HIP events and writes <run>/profile_data/gpu_actor_rank<r>.jsonl
+        self.profiler = None
+        if self.profile_ranges and self.device.type == "cuda":
+            from .gpu_profile import MoveProfiler
+
+            self.profiler = MoveProfiler(self.device, profile_dir, rank)
         self._use_graph = bool(system_config.USE_HIP_GRAPHS) and self.evaluator.graph_safe
         self.per_game_metrics = True
         self._grid_view = self.tree.nn_grid
@@ -266,11 +276,16 @@ class GpuSelfPlayActor:
         tree.move_stats.zero_()
         tree.census.zero_()
         rng = self._range
+        prof = self.profiler
+        if prof is not None:
+            prof.mark("move_start")
         rng("selfplay/root_eval")
         tree.prepare_roots()
         self._forward()
         tree.init_roots()
         rng(None)
+        if prof is not None:
+            prof.mark("root_done")
         rng("selfplay/waves")
         waves = self.waves_per_move
         tree.wave(consume=False, select=True)
@@ -288,6 +303,8 @@ class GpuSelfPlayActor:
                     self._steady_wave()
         tree.wave(consume=True, select=False)
         rng(None)
+        if prof is not None:
+            prof.mark("waves_done")
 
     def _range(self, name: str | None) -> None:
         """roctx range markers (visible in rocprofv3 --marker-trace) when profiling is switched on."""
@@ -316,6 +333,8 @@ class GpuSelfPlayActor:
         tree.reroot()
         added = self.replay.end_commit()
         self._range(None)
+        if self.profiler is not None:
+            self.profiler.mark("move_end")
         stats = tree.move_stats.cpu().numpy()
         census = tree.census_totals().cpu().numpy()
         ep_total = int(tree.ep_count.item())
@@ -339,6 +358,15 @@ class GpuSelfPlayActor:
         moves = int(stats[2])
         self.total_moves += moves
         self.total_episodes += new_eps
+        phase_ms: dict[str, float] = {}
+        if self.profiler is not None:
+            # every event of this move has completed: the copies above synchronised with the stream they were recorded on
+            slots = int(census[SLOT_NONE] + census[SLOT_EXPAND] + census[SLOT_TERMINAL] + census[SLOT_DEPTHCAP])
+            phase_ms = self.profiler.finish({
+                "games_moved": moves, "simulations": int(stats[4]), "episodes_finished": new_eps,
+                "leaf_share": round(float(census[SLOT_EXPAND]) / slots, 4) if slots else None,
+                "trainer_step": self.current_trainer_step,
+            })
         report = GpuMoveReport(
             moves=moves,
             simulations=int(stats[4]),
@@ -352,6 +380,7 @@ class GpuSelfPlayActor:
             per_game=per_game,
             slot_census={"none": int(census[SLOT_NONE]), "expand": int(census[SLOT_EXPAND]),
                          "terminal": int(census[SLOT_TERMINAL]), "depth_cap": int(census[SLOT_DEPTHCAP])},
+            phase_ms=phase_ms,
         )
         bad = int(census[CENSUS_NON_FINITE])
         if bad:

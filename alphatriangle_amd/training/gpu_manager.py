@@ -55,8 +55,13 @@ class GpuMoveSource:
                 self._ev_weights.record(main)
                 self.actor.begin_move()
                 self._train_stream.wait_event(self._ev_weights)
+                prof = getattr(self.actor, "profiler", None)
                 with torch.cuda.stream(self._train_stream):
+                    if prof is not None:
+                        prof.mark("learner_start", self._train_stream)
                     self.last_trained_steps = learn(quota)
+                    if prof is not None:
+                        prof.mark("learner_end", self._train_stream)
                     self._ev_trained.record(self._train_stream)
                 report = self.actor.finish_move(wait_event=self._ev_trained)
                 main.wait_event(self._ev_trained)

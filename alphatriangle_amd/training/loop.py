@@ -275,6 +275,8 @@ class TrainingLoop:
         if report.episodes_finished:
             self._emit("Progress/Episodes_Played", self.episodes_played)
         self._emit("Progress/Total_Simulations", self.total_simulations_run)
+        for key, ms in (getattr(report, "phase_ms", None) or {}).items():  # --profile: GPU time of the move's phases
+            self._emit("Perf/SelfPlay_" + key[:-3].title() + "_ms", float(ms))
 
     def _account(self, worker_id: int, item: Any) -> None:
         try:

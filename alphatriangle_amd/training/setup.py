@@ -112,9 +112,14 @@ def setup_training_components(
                 )
             buffer = DeviceReplayBuffer(buf_cfg, env_config, model_config, device, system_config)
             if not pure_learner:
+                profile_dir = None
+                if train_config.PROFILE_WORKERS:
+                    import os
+
+                    profile_dir = os.path.join(stats_actor.get_run_base_dir_str(), "profile_data")
                 gpu_actor = GpuSelfPlayActor(
                     env_config, model_config, mcts_config, train_config, system_config, neural_net, buffer, device,
-                    seed=train_config.RANDOM_SEED + rank * 1_000_003,
+                    seed=train_config.RANDOM_SEED + rank * 1_000_003, profile_dir=profile_dir, rank=rank,
                 )
         else:
             buffer = ExperienceBuffer(train_config)

@@ -361,3 +361,36 @@ def test_training_loop_on_gpu_colocated(tmp_path, overlap):
     assert code == 0
     ckpt_dir = tmp_path / "t" / "runs" / run / "checkpoints"
     assert any(p.suffix == ".pkl" for p in ckpt_dir.rglob("*")), "periodic / final checkpoint missing"
+
+
+def test_profiled_actor_leaves_a_per_move_gpu_timing_file(tmp_path):
+    """--profile on the GPU path: three moves leave three records in profile_data/gpu_actor_rank0.jsonl whose phases add
+    up to the move, and the move report carries the same numbers for the Perf/* metrics."""
+    import json
+
+    from alphatriangle_amd.config import AlphaTriangleMCTSConfig, EnvConfig, ModelConfig, SystemConfig, TrainConfig
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.rl.core.device_buffer import DeviceReplayBuffer
+    from alphatriangle_amd.rl.self_play.gpu_actor import GpuSelfPlayActor
+    from alphatriangle_amd.rl.self_play.gpu_profile import summarise
+
+    dev = torch.device("cuda")
+    env, mc = EnvConfig(), ModelConfig()
+    tc = TrainConfig(DEVICE="cuda", BUFFER_CAPACITY=20_000, MIN_BUFFER_SIZE_TO_TRAIN=256, PROFILE_WORKERS=True)
+    sc = SystemConfig(GAMES_PER_GPU=256, REPLAY_HBM_BUDGET_GB=2.0)
+    net = NeuralNetwork(mc, env, tc, dev, inference_dtype=sc.INFERENCE_DTYPE)
+    replay = DeviceReplayBuffer(tc, env, mc, dev, sc)
+    actor = GpuSelfPlayActor(env, mc, AlphaTriangleMCTSConfig(max_simulations=16, max_depth=5), tc, sc, net, replay, dev, seed=3,
+                             profile_dir=str(tmp_path / "profile_data"), rank=0)
+    reports = [actor.play_move() for _ in range(3)]
+    actor.profiler.close()
+    path = tmp_path / "profile_data" / "gpu_actor_rank0.jsonl"
+    rows = [json.loads(ln) for ln in path.read_text().splitlines() if ln.strip()]
+    assert len(rows) == 3 and [r["move"] for r in rows] == [0, 1, 2]
+    for r, rep in zip(rows, reports):
+        assert r["games_moved"] == rep.moves == 256 and r["simulations"] == rep.simulations
+        assert r["root_eval_ms"] > 0 and r["waves_ms"] > 0 and r["commit_ms"] > 0
+        assert abs(r["root_eval_ms"] + r["waves_ms"] + r["commit_ms"] - r["move_ms"]) < 0.05 * r["move_ms"] + 0.05
+        assert "learner_ms" not in r  # no overlapped learner in this run
+        assert rep.phase_ms["move_ms"] == r["move_ms"]
+    assert summarise(path)["phases"]["waves"]["n"] == 3
