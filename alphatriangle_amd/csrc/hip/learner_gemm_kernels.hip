@@ -31,6 +31,10 @@ struct Gemm3Args {
   // (b * h + y) * w + x.  Mode 2: B(k, n) = patch[k][n] (forward / data gradient, N = positions).  Mode 3:
   // B(k, n) = patch[n][k_off + k] (weight gradient, K = a chunk of positions starting at k_off = blockIdx.z * b_batch).
   int cin, nb, h, w;
+  // widest aligned access of each operand along its contiguous dimension: 4 (float4: strides, extents, base addresses all
+  // multiples of 4 floats), 2 (all even) or 1.  Narrower accesses mask per pair / per element, so that rows of any
+  // length and pitch work (the shared layer's 15 390 inputs, the value head's 51 atoms).
+  int va, vb, vc;
 };
 
 namespace {
@@ -50,6 +54,29 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
   lo = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
 }
 
+// Four consecutive floats at p of which the first `left` (may be <= 0 or > 4) exist, read in pieces of `vec` floats.
+__device__ __forceinline__ float4 load_quad(const float* p, int left, int vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec == 4) {
+    if (left > 0) v = *reinterpret_cast<const float4*>(p);
+  } else if (vec == 2) {
+    if (left > 0) {
+      const float2 a = *reinterpret_cast<const float2*>(p);
+      v.x = a.x; v.y = a.y;
+    }
+    if (left > 2) {
+      const float2 b = *reinterpret_cast<const float2*>(p + 2);
+      v.z = b.x; v.w = b.y;
+    }
+  } else {
+    if (left > 0) v.x = p[0];
+    if (left > 1) v.y = p[1];
+    if (left > 2) v.z = p[2];
+    if (left > 3) v.w = p[3];
+  }
+  return v;
+}
+
 // Global -> registers -> LDS for one ROWS x 32 operand tile.
 // KCONTIG: a thread takes float4s along k (row r, k-quad c) and stores each as one 8-byte piece per plane.
 // Otherwise the row dimension is the contiguous one: a thread takes a 4 x 4 block (k = 4 kq .. + 3, rows 4 rq .. + 3) as
@@ -60,22 +87,22 @@ struct TileLoader {
   static constexpr int kVec = KCONTIG ? ROWS * kBK / 4 / 256 : 4;  // float4 per thread
   static constexpr int kBlocks = 2 * ROWS;                         // 4 x 4 blocks per tile (row-contiguous form)
   float4 v[kVec];
-  __device__ __forceinline__ void load(const float* base, long long s_row, long long s_k, int row0, int n_rows, int k0, int K, int tid) {
+  __device__ __forceinline__ void load(const float* base, long long s_row, long long s_k, int row0, int n_rows, int k0, int K, int tid,
+                                       int vec) {
     if constexpr (KCONTIG) {
 #pragma unroll
       for (int i = 0; i < kVec; ++i) {
         const int id = tid + i * 256;
         const int r = id >> 3, c = id & 7;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < n_rows && k0 + c * 4 < K) v[i] = *reinterpret_cast<const float4*>(base + (long long)(row0 + r) * s_row + (k0 + c * 4));
+        const int left = row0 + r < n_rows ? K - (k0 + c * 4) : 0;
+        v[i] = load_quad(base + (long long)(row0 + r) * s_row + (k0 + c * 4), left, vec);
       }
     } else {
       const int kq = tid / (ROWS / 4), rq = tid % (ROWS / 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < kBlocks && row0 + rq * 4 < n_rows && k0 + kq * 4 + i < K)
-          v[i] = *reinterpret_cast<const float4*>(base + (long long)(k0 + kq * 4 + i) * s_k + (row0 + rq * 4));
+        const int left = (tid < kBlocks && k0 + kq * 4 + i < K) ? n_rows - (row0 + rq * 4) : 0;
+        v[i] = load_quad(base + (long long)(k0 + kq * 4 + i) * s_k + (row0 + rq * 4), left, vec);
       }
     }
   }
@@ -272,10 +299,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Args g) {
   const long long a_row = g.a_row, a_k = g.a_k, b_row = g.b_col, b_k = g.b_k;
   auto load = [&](auto P, int k0) {
     constexpr int p = decltype(P)::value;
-    la[p].load(A, a_row, a_k, m0, g.M, k0, g.K, tid);
+    la[p].load(A, a_row, a_k, m0, g.M, k0, g.K, tid, g.va);
     if constexpr (B_MODE == 2) lb[p].load(g, B, k0, tid);
     else if constexpr (B_MODE == 3) lb[p].load(g, B, k_off, k0, tid);
-    else lb[p].t.load(B, b_row, b_k, n0, g.N, k0, g.K, tid);
+    else lb[p].t.load(B, b_row, b_k, n0, g.N, k0, g.K, tid, g.vb);
   };
   auto store = [&](auto P, unsigned char* buf) {
     constexpr int p = decltype(P)::value;
@@ -329,13 +356,25 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Args g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + (wn * 4 + j) * 16 + q4 * 4;
-      if (n >= g.N) continue;  // N is a multiple of 4
+      const int left = g.N - n;
+      if (left <= 0) continue;
       float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       if (g.bias != nullptr) {
-        const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+        const float4 b = load_quad(g.bias + n, left, g.vc);
         o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
       }
-      *reinterpret_cast<float4*>(C + (long long)m * g.ldc + n) = o;
+      float* c = C + (long long)m * g.ldc + n;
+      if (g.vc == 4) {
+        *reinterpret_cast<float4*>(c) = o;
+      } else if (g.vc == 2) {
+        *reinterpret_cast<float2*>(c) = make_float2(o.x, o.y);
+        if (left > 2) *reinterpret_cast<float2*>(c + 2) = make_float2(o.z, o.w);
+      } else {
+        c[0] = o.x;
+        if (left > 1) c[1] = o.y;
+        if (left > 2) c[2] = o.z;
+        if (left > 3) c[3] = o.w;
+      }
     }
   }
 }
@@ -365,22 +404,26 @@ int launch_for_m(const Gemm3Args& g, int batch, bool a_kc, int b_mode, hipStream
 extern "C" {
 
 // C[b] = A[b] B[b] (+ bias) for b < batch, fp32 in / out, three-pass bf16 MFMA.  Strides in elements; exactly one of
-// (a_row, a_k) and one of (b_k, b_col) must be 1, the other a multiple of 4; all base addresses, batch strides and ldc
-// multiples of 4 elements (16-byte vector accesses); N a multiple of 4.  M, N, K need not be multiples of the tile sizes.
+// (a_row, a_k) and one of (b_k, b_col) must be 1.  Each operand is accessed with the widest vectors its pitch, extent
+// along the contiguous dimension, base address and batch stride allow (16, 8 or 4 bytes); M, N, K are arbitrary.
 int atri_gemm3(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long long a_row, long long a_k,
                long long b_k, long long b_col, long long ldc, int batch, long long a_batch, long long b_batch, long long c_batch,
                hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
   const bool a_kc = a_k == 1, b_kc = b_k == 1;
   if ((!a_kc && a_row != 1) || (!b_kc && b_col != 1)) return -10;
-  if (((a_kc ? a_row : a_k) & 3) || ((b_kc ? b_col : b_k) & 3) || (ldc & 3) || (N & 3)) return -11;
-  if ((a_batch & 3) || (b_batch & 3) || (c_batch & 3)) return -11;
-  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias) & 15) return -12;
-  if (a_kc && (K & 3)) return -13;   // float4 along k
-  if (!a_kc && (M & 3)) return -13;  // float4 along m
-  if (b_kc && (K & 3)) return -13;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias) & 3) return -12;
   if (batch > 65535) return -14;
-  Gemm3Args g{A, B, C, bias, a_row, a_k, b_k, b_col, ldc, a_batch, b_batch, c_batch, M, N, K, 0, 0, 0, 0};
+  // widest vector (in floats) that divides every quantity an access of the operand depends on
+  auto width = [](long long pitch, long long extent, long long batch_stride, uintptr_t p0, uintptr_t p1) {
+    const unsigned long long bits = (unsigned long long)pitch | (unsigned long long)extent | (unsigned long long)batch_stride |
+                                    (unsigned long long)(p0 >> 2) | (unsigned long long)(p1 >> 2);
+    return (bits & 3) == 0 ? 4 : (bits & 1) == 0 ? 2 : 1;
+  };
+  Gemm3Args g{A, B, C, bias, a_row, a_k, b_k, b_col, ldc, a_batch, b_batch, c_batch, M, N, K, 0, 0, 0, 0, 4, 4, 4};
+  g.va = width(a_kc ? a_row : a_k, a_kc ? K : M, a_batch, (uintptr_t)A, 0);
+  g.vb = width(b_kc ? b_col : b_k, b_kc ? K : N, b_batch, (uintptr_t)B, 0);
+  g.vc = width(ldc, N, c_batch, (uintptr_t)C, (uintptr_t)bias);
   return launch_for_m(g, batch, a_kc, b_kc ? 1 : 0, stream);
 }
 
@@ -401,6 +444,7 @@ int atri_conv3_gemm(const float* A, const float* X, float* C, int M, int cin, in
   g.A = A; g.B = X; g.C = C; g.bias = nullptr;
   g.a_row = lda; g.a_k = 1;
   g.M = M; g.cin = cin; g.nb = nb; g.h = h; g.w = w;
+  g.va = g.vb = g.vc = 4;
   if (!transposed) {
     g.N = (int)positions; g.K = cin * 9; g.ldc = positions;
     return launch_for_m(g, 1, true, 2, stream);

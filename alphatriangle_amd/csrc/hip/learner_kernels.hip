@@ -404,6 +404,41 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   if (wave == 0 && col < F) out[col] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
+// The same sum for many partial rows: 16 columns per workgroup, the rows spread over 16 thread groups (64 columns per
+// workgroup leave four workgroups for a 256-wide LayerNorm gradient, each walking 500 rows four at a time).
+__global__ __launch_bounds__(256) void colsum_final16_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             int blocks, int F) {
+  __shared__ float sm[16][17];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < F) {
+    int b = rg;
+    for (; b + 48 < blocks; b += 64) {
+      a0 += partial[(size_t)b * F + col];
+      a1 += partial[(size_t)(b + 16) * F + col];
+      a2 += partial[(size_t)(b + 32) * F + col];
+      a3 += partial[(size_t)(b + 48) * F + col];
+    }
+    for (; b < blocks; b += 16) a0 += partial[(size_t)b * F + col];
+  }
+  sm[rg][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rg == 0 && col < F) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sm[i][cl];
+    out[col] = t;
+  }
+}
+
+static inline void launch_colsum_final(const float* partial, float* out, int blocks, int F, hipStream_t s) {
+  if (blocks >= 48)
+    hipLaunchKernelGGL(colsum_final16_kernel, dim3((F + 15) / 16), dim3(256), 0, s, partial, out, blocks, F);
+  else
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 63) / 64), dim3(256), 0, s, partial, out, blocks, F);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm forward / backward for the learner (rows x D, D = 8 * LPR with LPR lanes per row, bf16 or fp32 rows,
 // fp32 statistics).  torch's kernels take 34 us (forward), 40 + 28 us (backward) per call on [30720, 128] and run in
@@ -742,6 +777,10 @@ int atri_per_priorities(double* tree, long long P, const int* idx, const float* 
 int atri_colsum(const void* g, int is_bf16, float* partial, float* out, int N, int F, int rows_per_block,
                 hipStream_t s) {
   if (N <= 0 || F <= 0 || rows_per_block <= 0) return (int)hipErrorInvalidValue;
+  if (!is_bf16 && N <= 1024) {  // few rows (the heads' [batch, features] gradients): the second stage alone adds them all
+    launch_colsum_final((const float*)g, out, N, F, s);
+    return (int)hipGetLastError();
+  }
   const int blocks = (N + rows_per_block - 1) / rows_per_block;
   dim3 grid((F + 63) / 64, blocks);
   if (is_bf16)
@@ -750,7 +789,7 @@ int atri_colsum(const void* g, int is_bf16, float* partial, float* out, int N, i
   else
     hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)g, partial, N, F,
                        rows_per_block);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 63) / 64), dim3(256), 0, s, partial, out, blocks, F);
+  launch_colsum_final(partial, out, blocks, F, s);
   return (int)hipGetLastError();
 }
 
@@ -797,7 +836,7 @@ int atri_ln_bwd(const void* x, const void* dy, int is_bf16, int dy_bf16, const f
   }
 #undef ATRI_LN_BWD
   // partial is [blocks][2][D]: one column sum over blocks of the 2 * D wide rows gives dgamma | dbeta
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, partial, dgamma, blocks, 2 * D);
+  launch_colsum_final(partial, dgamma, blocks, 2 * D, s);
   (void)dbeta;  // dgamma and dbeta are the two halves of one [2 * D] buffer
   return (int)hipGetLastError();
 }

@@ -52,6 +52,11 @@ FP32_GEMM_ON_BF16_CORES = True
 # 75 % slower products (the loader's per-value address and bounds arithmetic costs more than the patch traffic it saves;
 # the plain products already run at the speed their patch matrix can be read at).  SystemConfig.LEARNER_PATCH_FREE_CONV.
 PATCH_FREE_CONV = False
+# 3x3 / padding-1 convolutions of the fp32 path (forward and data gradient) on the board-per-workgroup kernel
+# (ops.hip_learner.conv3_cm): the input is staged once into LDS and the nine taps are shifted reads of it, where the
+# GEMM-lowered form writes and reads a nine times larger patch matrix.  The weight gradient still multiplies with the
+# patch matrix, which the backward pass then builds itself.  False restores the GEMM-lowered products (A/B runs, tests).
+DIRECT_CONV = True
 
 
 def _mm(a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
@@ -67,12 +72,46 @@ def _mm(a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None) -> t
     return torch.bmm(a, b) if a.dim() == 3 else a @ b
 
 
-def _split_count(n: int, limit: int = 32, min_chunk: int = 512) -> int:
-    """Largest divisor of ``n`` that is at most ``limit`` and leaves chunks of at least ``min_chunk``."""
+def _sum_parts(parts: torch.Tensor) -> torch.Tensor:
+    """Sum of the split-K slices ``parts [S, ...]`` in the gradient dtype (one in-tree launch on the GPU)."""
+    if parts.shape[0] == 1 and parts.dtype == _grad_dtype(parts):
+        return parts[0]
+    if parts.is_cuda and parts.is_contiguous() and parts.dtype in (torch.float32, torch.bfloat16):
+        from ..ops import hip_learner
+
+        if hip_learner.available():
+            return hip_learner.sum_slices(parts)
+    return parts.sum(0, dtype=_grad_dtype(parts))
+
+
+def _flipped_filter(weight: torch.Tensor) -> torch.Tensor:
+    """``[Cin, Cout * kh * kw]`` operand of a convolution's data gradient (flipped taps, channels swapped)."""
+    cout, cin, kh, kw = weight.shape
+    if weight.is_cuda and weight.dtype in (torch.float32, torch.bfloat16):
+        from ..ops import hip_learner
+
+        if hip_learner.available():
+            return hip_learner.conv_wt(weight)
+    return weight.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * kh * kw)
+
+
+def _split_count(n: int, limit: int = 32, min_chunk: int = 512, step: int = 1) -> int:
+    """Largest divisor of ``n`` that is at most ``limit`` and leaves chunks of at least ``min_chunk`` (whole multiples of
+    ``step`` when such a divisor exists)."""
+    fallback = 1
     for s in range(min(limit, max(1, n // min_chunk)), 1, -1):
         if n % s == 0:
-            return s
-    return 1
+            if (n // s) % step == 0:
+                return s
+            fallback = max(fallback, s)
+    return fallback
+
+
+def _linear_wgrad_slices(n: int, fp32_kernel: bool) -> int:
+    """Slices of the ``n`` rows a linear layer's weight gradient reduces over.  The in-tree fp32 GEMM gets one workgroup
+    per (slice, 128 x 128 output tile) and these gradients have one to three tiles, so it takes about 120 slices of whole
+    32-row steps to fill 256 compute units (32 slices: 56 us per product at 30 720 rows)."""
+    return _split_count(n, 128, 192, 32) if fp32_kernel else _split_count(n)
 
 
 def _patch_matrix(x: torch.Tensor, kh: int, kw: int, ph: int, pw: int) -> torch.Tensor:
@@ -132,7 +171,7 @@ class _ConvGemm(torch.autograd.Function):
             g2 = grad_out.permute(1, 0, 2, 3).reshape(cout, n)
             s = _split_count(n)
             parts = torch.bmm(g2.view(cout, s, n // s).transpose(0, 1), cols.view(k, s, n // s).permute(1, 2, 0))
-            d_w = parts.sum(0, dtype=_grad_dtype(parts)).view(cout, cin, kh, kw)
+            d_w = _sum_parts(parts).view(cout, cin, kh, kw)
         if ctx.needs_input_grad[0]:
             g_cols = _patch_matrix(grad_out, kh, kw, kh - 1 - ph, kw - 1 - pw)  # [Cout*kh*kw, B*H*W]
             w_t = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * kh * kw)
@@ -169,6 +208,11 @@ class _ConvGemmCM(torch.autograd.Function):
             if ctx.implicit:
                 ctx.save_for_backward(x, weight)
                 return hip_learner.conv3_mm(w2, x).view(cout, b, oh, ow)
+            ctx.direct = bool(FP32_GEMM_ON_BF16_CORES and DIRECT_CONV and (kh, kw, ph, pw) == (3, 3, 1, 1) and weight.dtype == torch.float32
+                              and hip_learner.conv3_cm_supported(x, cout))
+            if ctx.direct:
+                ctx.save_for_backward(x, weight)
+                return hip_learner.conv3_cm(x, hip_learner.conv3_pack(weight, False), cout)
             if kh == 1 and kw == 1:
                 cols = x.reshape(cin, b * h * w)
             elif x.is_cuda:
@@ -183,11 +227,14 @@ class _ConvGemmCM(torch.autograd.Function):
     def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
         from ..ops import hip_learner
 
-        cols, weight = ctx.saved_tensors  # with ctx.implicit, `cols` is the layer input itself
+        cols, weight = ctx.saved_tensors  # with ctx.implicit / ctx.direct, `cols` is the layer input itself
         b, h, w, ph, pw = ctx.geom
         cout, cin, kh, kw = weight.shape
         g = grad_out.contiguous()
         d_x = d_w = None
+        direct = getattr(ctx, "direct", False)
+        if direct and ctx.needs_input_grad[1]:
+            cols = hip_learner.patch_matrix_cm(cols, kh, kw, ph, pw)  # the weight gradient's operand, built here instead of kept
         if ctx.needs_input_grad[1]:
             n = b * h * w if ctx.implicit else cols.shape[1]
             g2 = g.view(cout, n)
@@ -197,12 +244,14 @@ class _ConvGemmCM(torch.autograd.Function):
             else:
                 k = cols.shape[0]
                 parts = _mm(g2.view(cout, s, n // s).transpose(0, 1), cols.view(k, s, n // s).permute(1, 2, 0))
-            d_w = parts.sum(0, dtype=_grad_dtype(parts)).view(cout, cin, kh, kw)
+            d_w = _sum_parts(parts).view(cout, cin, kh, kw)
         if ctx.needs_input_grad[0]:
             if kh == 1 and kw == 1:
                 d_x = _mm(weight.reshape(cout, cin).t(), g.view(cout, -1)).view(cin, b, h, w)
+            elif direct and hip_learner.conv3_cm_supported(g, cin):
+                d_x = hip_learner.conv3_cm(g, hip_learner.conv3_pack(weight, True), cin)
             else:
-                w_t = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * kh * kw)
+                w_t = _flipped_filter(weight)
                 if ctx.implicit and hip_learner.conv3_supported(g, w_t):
                     d_x = hip_learner.conv3_mm(w_t, g).view(cin, b, h, w)
                 else:
@@ -338,13 +387,13 @@ class _SplitKLinear(torch.autograd.Function):
         x2, weight = ctx.saved_tensors
         g = grad_out.contiguous()
         n, out_f = g.shape
-        s = _split_count(n)
+        s = _linear_wgrad_slices(n, bool(FP32_GEMM_ON_BF16_CORES and g.is_cuda and g.dtype == torch.float32))
         gs = g.view(s, n // s, out_f)
         d_x = _mm(g, weight) if ctx.needs_input_grad[0] else None
         d_w = None
         if ctx.needs_input_grad[1]:
             parts = _mm(gs.transpose(1, 2), x2.reshape(s, n // s, x2.shape[1]))
-            d_w = parts.sum(0, dtype=_grad_dtype(parts))
+            d_w = _sum_parts(parts)
         d_b = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if g.is_cuda and g.dtype in (torch.bfloat16, torch.float32):
@@ -361,6 +410,94 @@ def _linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | Non
     lead = x.shape[:-1]
     y = _SplitKLinear.apply(x.reshape(-1, x.shape[-1]), weight, bias)
     return y.view(*lead, weight.shape[0])
+
+
+def _k_slices(k: int, limit: int = 128, min_chunk: int = 128) -> int:
+    """Number of slices a ``k``-long dot product is cut into: the largest divisor of ``k`` up to ``limit`` whose chunks are
+    multiples of four of at least ``min_chunk`` values."""
+    for s in range(min(limit, max(1, k // min_chunk)), 1, -1):
+        if k % s == 0 and (k // s) % 4 == 0:
+            return s
+    return 1
+
+
+class _SharedFc(torch.autograd.Function):
+    """First layer after the body: ``y = [body | other] @ W^T + b`` without the concatenation (fp32, GPU).
+
+    ``body [B, Fb]`` (15 360 features at the default size) and ``other [B, Fo]`` (30) multiply their own column blocks of
+    ``W [out, Fb + Fo]``.  With 256 rows and 128 outputs the product has two output tiles, so the long dot product is
+    cut into slices that run as one batched launch of ``ops.hip_learner.mm3`` and are added (with the bias) by
+    ``sum_slices``; the small block is one more slice.  The backward pass writes both column blocks of the weight
+    gradient in place and produces no gradient for ``other`` (a network input).
+    Reference layer: alphatriangle/nn/model.py:180-196.
+    """
+
+    @staticmethod
+    def forward(ctx, body: torch.Tensor, other: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:  # noqa: ANN001
+        from ..ops import hip_learner
+
+        body, other = body.contiguous(), other.contiguous()
+        n, fb = body.shape
+        out_f = weight.shape[0]
+        s = _k_slices(fb)
+        chunk = fb // s
+        parts = torch.empty(s + 1, n, out_f, dtype=torch.float32, device=body.device)
+        w_body, w_other = weight[:, :fb], weight[:, fb:]
+        ok = hip_learner.mm3(body.view(n, s, chunk).transpose(0, 1), w_body.view(out_f, s, chunk).permute(1, 2, 0), out=parts[:s])
+        ok2 = hip_learner.mm3(other, w_other.t(), out=parts[s])
+        if ok is None or ok2 is None:
+            raise RuntimeError("_SharedFc: operands rejected by the fp32-grade GEMM")
+        ctx.save_for_backward(body, other, weight)
+        ctx.has_bias = bias is not None
+        return hip_learner.sum_slices(parts, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        body, other, weight = ctx.saved_tensors
+        g = grad_out.contiguous()
+        fb = body.shape[1]
+        d_body = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_body = hip_learner.mm3(g, weight[:, :fb])
+        if ctx.needs_input_grad[2]:
+            d_w = torch.empty_like(weight)
+            hip_learner.mm3(g.t(), body, out=d_w[:, :fb])
+            hip_learner.mm3(g.t(), other, out=d_w[:, fb:])
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            d_b = hip_learner.colsum(g)
+        return d_body, None, d_w, d_b
+
+
+class _Bn1dAct(torch.autograd.Function):
+    """Training-mode BatchNorm1d (+ activation) on ``[B, C]`` rows: one launch forward, one backward
+    (``ops.hip_learner.bn1d_*``) in place of the library's statistics / apply / activation kernels and their backward
+    twins (alphatriangle/nn/model.py:183-189, 201-207, 214-220 build these layers)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, act_id):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        w32, b32 = weight.float().contiguous(), bias.float().contiguous()
+        momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+        track = bn.track_running_stats and bn.running_mean is not None
+        x = x.contiguous()
+        y, mean, rstd = hip_learner.bn1d_forward(
+            x, w32, b32, float(bn.eps), momentum, bn.running_mean if track else None, bn.running_var if track else None,
+            bn.num_batches_tracked if track else None, act_id,
+        )
+        ctx.save_for_backward(x, w32, b32, mean, rstd)
+        ctx.act_id = act_id
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        x, w32, b32, mean, rstd = ctx.saved_tensors
+        dx, dg, db = hip_learner.bn1d_backward(x, grad_out, w32, b32, mean, rstd, ctx.act_id)
+        return dx, dg, db, None, None
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -802,8 +939,64 @@ class AlphaTriangleNet(nn.Module):
             return tokens.permute(1, 0, 2).flatten(1)
         return x.reshape(x.size(0), -1)
 
+    fused_tail = True  # learner fast path: shared layer and heads on the in-tree GEMM / BatchNorm1d kernels (tests flip this)
+
+    def _tail_ok(self, body: torch.Tensor, other: torch.Tensor) -> bool:
+        if not (self.fused_tail and self.training and torch.is_grad_enabled() and body.is_cuda and other.is_cuda and body.dim() == 2):
+            return False
+        if torch.is_autocast_enabled("cuda"):
+            if torch.get_autocast_dtype("cuda") != torch.bfloat16:
+                return False
+        elif body.dtype != torch.float32 or other.dtype != torch.float32:
+            return False
+        from ..ops import hip_learner
+
+        return bool(hip_learner.available())
+
+    def _mlp_apply(self, seq: nn.Sequential, x: torch.Tensor, other: torch.Tensor | None = None) -> torch.Tensor:
+        """``seq`` (Linear [-> BatchNorm1d] -> activation, ..., [Linear]) on ``[B, F]`` rows through the learner's kernels.
+        With ``other`` the first Linear multiplies ``[x | other]`` (the shared layer's input) without concatenating."""
+        from ..ops import hip_learner
+
+        mods = list(seq)
+        i = 0
+        if other is not None and other.shape[1] == 0:
+            other = None
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, nn.Linear):
+                if other is not None:
+                    if x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and FP32_GEMM_ON_BF16_CORES:
+                        x = _SharedFc.apply(x, other, m.weight, m.bias)
+                    else:
+                        x = _linear_rows(torch.cat([x, other.to(x.dtype)], dim=1), m.weight, m.bias)
+                    other = None
+                else:
+                    x = _linear_rows(x, m.weight, m.bias)
+                i += 1
+                continue
+            if isinstance(m, nn.BatchNorm1d) and m.training and m.affine and hip_learner.bn1d_supported(x):
+                fuse = nxt is not None and not isinstance(nxt, (nn.Linear, nn.BatchNorm1d)) and _act_id(nxt) not in (None, 0)
+                x = _Bn1dAct.apply(x, m.weight, m.bias, m, _act_id(nxt) if fuse else 0)
+                i += 2 if fuse else 1
+                continue
+            if _act_id(m) not in (None, 0) and hip_learner.act_dropout_supported(x):
+                x = _ActDropout.apply(x, 0.0, _act_id(m))
+                i += 1
+                continue
+            x = m(x)
+            i += 1
+        if other is not None:  # no Linear in the shared stack: the heads see the concatenation itself
+            x = torch.cat([x, other.to(x.dtype)], dim=1)
+        return x
+
     def forward(self, grid_state: torch.Tensor, other_features: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """Returns ``(policy_logits [B, A], value_logits [B, atoms])``."""
-        feat = torch.cat([self.body(grid_state), other_features], dim=1)
+        body = self.body(grid_state)
+        if self._tail_ok(body, other_features):
+            shared = self._mlp_apply(self.shared_fc, body, other_features)
+            return self._mlp_apply(self.policy_head, shared), self._mlp_apply(self.value_head, shared)
+        feat = torch.cat([body, other_features], dim=1)
         shared = self.shared_fc(feat)
         return self.policy_head(shared), self.value_head(shared)

@@ -44,17 +44,25 @@ class _FusedLoss(torch.autograd.Function):
         )
         ctx.save_for_backward(dpl, dvl)
         ctx.in_dtypes = (plog.dtype, vlog.dtype)
-        policy_loss = (pce * iw).mean()
-        value_loss = (vce * iw).mean()
-        entropy = ent.mean() if we > 0 else torch.zeros((), device=dev)
-        total = wp * policy_loss + wv * value_loss - we * entropy
+        scalars = torch.empty(4, dtype=torch.float32, device=dev)  # total, policy, value, entropy: one launch for all four
+        hb.call("atri_loss_reduce", hb.ptr(pce), hb.ptr(vce), hb.ptr(ent), hb.ptr(iw), hb.i32(B), hb.f32(wp), hb.f32(wv), hb.f32(we),
+                hb.ptr(scalars))
+        total, policy_loss, value_loss, entropy = scalars[0], scalars[1], scalars[2], scalars[3]
         ctx.mark_non_differentiable(policy_loss, value_loss, entropy, vce)
+        ctx.set_materialize_grads(False)  # no zero tensors for the outputs nobody differentiates
         return total, policy_loss, value_loss, entropy, vce
 
     @staticmethod
     def backward(ctx, g_total, *_unused):  # noqa: ANN001
         dpl, dvl = ctx.saved_tensors
         pd, vd = ctx.in_dtypes
+        if g_total is None:
+            return (None,) * 10
+        if pd == vd and pd in (torch.float32, torch.bfloat16) and g_total.numel() == 1:
+            gp, gv = torch.empty_like(dpl, dtype=pd), torch.empty_like(dvl, dtype=vd)
+            hb.call("atri_scale_pair", hb.ptr(dpl), hb.i64(dpl.numel()), hb.ptr(dvl), hb.i64(dvl.numel()),
+                    hb.ptr(g_total.detach().float().contiguous()), hb.ptr(gp), hb.ptr(gv), hb.i32(1 if pd == torch.bfloat16 else 0))
+            return gp, gv, None, None, None, None, None, None, None, None
         return (dpl * g_total).to(pd), (dvl * g_total).to(vd), None, None, None, None, None, None, None, None
 
 
@@ -95,7 +103,7 @@ def colsum(g: torch.Tensor) -> torch.Tensor:
     if g.dim() != 2 or not g.is_contiguous() or g.dtype not in (torch.bfloat16, torch.float32):
         raise ValueError(f"colsum needs a contiguous 2-D bf16/fp32 matrix, got {tuple(g.shape)} {g.dtype}")
     n, f = g.shape
-    rows_per_block = 512 if n >= 8192 else 64
+    rows_per_block = 128 if n >= 8192 else 64  # 240 row blocks at 30 720 rows: enough workgroups to hide the load latency
     blocks = (n + rows_per_block - 1) // rows_per_block
     partial = torch.empty(blocks * f, dtype=torch.float32, device=g.device)
     out = torch.empty(f, dtype=torch.float32, device=g.device)
@@ -142,9 +150,33 @@ def layer_norm_backward(x2: torch.Tensor, dy2: torch.Tensor, weight: torch.Tenso
 
 
 # ---------------------------------------------------------------- dropout fused with its neighbours
+_seed_pool: dict[int, list] = {}  # device index -> [int64 seeds of the running step, next unused]
+SEEDS_PER_STEP = 64
+
+
+def _dev_index(device: torch.device | str | int) -> int:
+    d = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def begin_step_seeds(device: torch.device | str | int) -> None:
+    """Draw the dropout seeds of one forward pass with ONE generator call; every dropout site then takes its own element
+    (:func:`_drop_seed`) instead of launching a generator kernel of its own (eight per step for the default network)."""
+    _seed_pool[_dev_index(device)] = [torch.randint(0, 2**62, (SEEDS_PER_STEP,), dtype=torch.int64, device=device), 0]
+
+
+def end_step_seeds(device: torch.device | str | int) -> None:
+    _seed_pool.pop(_dev_index(device), None)
+
+
 def _drop_seed(device: torch.device) -> torch.Tensor:
     """One int64 on the device from torch's generator: ``torch.manual_seed`` governs it, and a captured step draws a
-    new one on every replay."""
+    new one on every replay.  Inside :func:`begin_step_seeds` / :func:`end_step_seeds` it is a view of that step's draw."""
+    ent = _seed_pool.get(_dev_index(device))
+    if ent is not None and ent[1] < ent[0].numel():
+        i = ent[1]
+        ent[1] = i + 1
+        return ent[0][i : i + 1]
     return torch.randint(0, 2**62, (1,), dtype=torch.int64, device=device)
 
 
@@ -273,25 +305,27 @@ def bn_act_cm_backward(x: torch.Tensor, residual: torch.Tensor | None, dy: torch
 
 # ---------------------------------------------------------------- fp32 GEMM on the bf16 matrix cores (three passes)
 def _gemm3_layout(t: torch.Tensor) -> tuple[int, int] | None:
-    """(row stride, column stride) of the last two dimensions when one of them is 1 and the other a multiple of 4."""
+    """(row stride, column stride) of the last two dimensions when one of them is the contiguous one."""
     sr, sc = int(t.stride(-2)), int(t.stride(-1))
     if t.shape[-1] == 1:
         sc = 1 if sr != 1 else sc
     if t.shape[-2] == 1:
         sr = 1 if sc != 1 else sr
-    if sc == 1 and sr % 4 == 0 and sr >= t.shape[-1]:
+    if sc == 1 and sr >= t.shape[-1]:
         return sr, 1
-    if sr == 1 and sc % 4 == 0 and sc >= t.shape[-2]:
+    if sr == 1 and sc >= t.shape[-2]:
         return 1, sc
     return None
 
 
-def mm3(a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor | None:
+def mm3(a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor | None:
     """``a @ b (+ bias)`` for fp32 CUDA operands through ``gemm3_kernel`` (fp32-grade: three bf16 MFMA passes over (hi, lo)
     splits), or ``None`` when the operands do not fit it (the caller then uses the library GEMM).
 
-    ``a`` is ``[M, K]`` or ``[S, M, K]``, ``b`` is ``[K, N]`` or ``[S, K, N]`` (batched for split-K weight gradients); either
-    dimension of each matrix may be the contiguous one, so transposed views need no copy.
+    ``a`` is ``[M, K]`` or ``[S, M, K]``, ``b`` is ``[K, N]`` or ``[S, K, N]`` (batched for split-K products); either
+    dimension of each matrix may be the contiguous one, so transposed views and column slices need no copy, and pitches
+    or extents that are not multiples of four floats only narrow the kernel's vector accesses.  ``out`` (fp32, last
+    dimension contiguous, e.g. a column block of a larger matrix) receives the product instead of a new tensor.
     """
     if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == b.dim() and a.dim() in (2, 3) and available()):
         return None
@@ -300,23 +334,118 @@ def mm3(a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None) -> t
         return None
     m, k = int(a.shape[-2]), int(a.shape[-1])
     n = int(b.shape[-1])
-    if int(b.shape[-2]) != k or n % 4 or min(m, n, k) < 1:
+    if int(b.shape[-2]) != k or min(m, n, k) < 1:
         return None
     la, lb = _gemm3_layout(a), _gemm3_layout(b)
     if la is None or lb is None:
         return None
-    a_kc, b_kc = la[1] == 1, lb[0] == 1
-    if (a_kc and k % 4) or (not a_kc and m % 4) or (b_kc and k % 4):
-        return None
     a_bs = int(a.stride(0)) if a.dim() == 3 else 0
     b_bs = int(b.stride(0)) if b.dim() == 3 else 0
-    if a_bs % 4 or b_bs % 4 or a.data_ptr() % 16 or b.data_ptr() % 16:
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != n or not bias.is_contiguous()):
         return None
-    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != n or not bias.is_contiguous() or bias.data_ptr() % 16):
-        return None
-    out = torch.empty((batch, m, n) if a.dim() == 3 else (m, n), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty((batch, m, n) if a.dim() == 3 else (m, n), dtype=torch.float32, device=a.device)
+    elif (out.dtype != torch.float32 or out.device != a.device or tuple(out.shape) != ((batch, m, n) if a.dim() == 3 else (m, n))
+          or out.stride(-1) != 1 or out.stride(-2) < n):
+        raise ValueError("mm3: `out` must be an fp32 tensor of the product's shape with a contiguous last dimension")
+    ldc = int(out.stride(-2))
+    c_bs = int(out.stride(0)) if out.dim() == 3 else m * n
     hb.call("atri_gemm3", hb.ptr(a), hb.ptr(b), hb.ptr(out), hb.ptr(bias), hb.i32(m), hb.i32(n), hb.i32(k), hb.i64(la[0]), hb.i64(la[1]),
-            hb.i64(lb[0]), hb.i64(lb[1]), hb.i64(n), hb.i32(batch), hb.i64(a_bs), hb.i64(b_bs), hb.i64(m * n))
+            hb.i64(lb[0]), hb.i64(lb[1]), hb.i64(ldc), hb.i32(batch), hb.i64(a_bs), hb.i64(b_bs), hb.i64(c_bs))
+    return out
+
+
+def sum_slices(parts: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """fp32 sum over the first dimension of contiguous ``parts [S, ...]`` (fp32 or bf16) in one launch, plus ``bias`` along the
+    last dimension: the reduction half of a split-K product (``sum_slices_kernel``)."""
+    if not parts.is_contiguous() or parts.dtype not in (torch.float32, torch.bfloat16) or parts.dim() < 2:
+        raise ValueError("sum_slices needs a contiguous fp32 / bf16 tensor [S, ...]")
+    s = int(parts.shape[0])
+    out = torch.empty(parts.shape[1:], dtype=torch.float32, device=parts.device)
+    period = 0
+    if bias is not None:
+        if bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != parts.shape[-1]:
+            raise ValueError("sum_slices: bias must be a contiguous fp32 vector over the last dimension")
+        period = int(bias.numel())
+    hb.call("atri_sum_slices", hb.ptr(parts), hb.i32(1 if parts.dtype == torch.bfloat16 else 0), hb.ptr(out), hb.i32(s), hb.i64(out.numel()),
+            hb.ptr(bias), hb.i32(period))
+    return out
+
+
+def bn1d_supported(x: torch.Tensor) -> bool:
+    return bool(x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[0] >= 1 and available())
+
+
+def bn1d_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, momentum: float,
+                 running_mean: torch.Tensor | None, running_var: torch.Tensor | None, num_batches: torch.Tensor | None,
+                 act: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Training-mode BatchNorm1d (+ activation) over the rows of ``x [B, C]`` in one launch: ``(y, batch_mean, batch_rstd)``;
+    the running statistics and the batch counter are updated in place (unbiased variance, like ``torch.nn.BatchNorm1d``)."""
+    x = x.contiguous()
+    b, c = (int(v) for v in x.shape)
+    y = torch.empty_like(x)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    hb.call("atri_bn1d_fwd", hb.ptr(x), hb.i32(1 if x.dtype == torch.bfloat16 else 0), hb.ptr(gamma), hb.ptr(beta), hb.i32(b), hb.i32(c),
+            hb.f32(eps), hb.f32(momentum), hb.ptr(running_mean), hb.ptr(running_var), hb.ptr(num_batches), hb.ptr(y), hb.ptr(mean),
+            hb.ptr(rstd), hb.i32(act))
+    return y, mean, rstd
+
+
+def bn1d_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
+                  act: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``(dx, dgamma, dbeta)`` of :func:`bn1d_forward` in one launch."""
+    b, c = (int(v) for v in x.shape)
+    dy = dy.to(x.dtype).contiguous()
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    hb.call("atri_bn1d_bwd", hb.ptr(x), hb.ptr(dy), hb.i32(1 if x.dtype == torch.bfloat16 else 0), hb.ptr(gamma), hb.ptr(beta), hb.ptr(mean),
+            hb.ptr(rstd), hb.i32(b), hb.i32(c), hb.i32(act), hb.ptr(dx), hb.ptr(dgamma), hb.ptr(dbeta))
+    return dx, dgamma, dbeta
+
+
+def conv3_cm_supported(x: torch.Tensor, cout: int) -> bool:
+    """True when :func:`conv3_cm` convolves channel-major ``x [Cin, B, H, W]`` (fp32, contiguous) into ``cout`` channels."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and available()):
+        return False
+    cin, nb, h, w = (int(v) for v in x.shape)
+    fn = getattr(hb.lib(), "atri_conv3_cm_supported")
+    fn.restype = C.c_int
+    return bool(nb >= 1 and cin * nb * h * w < 2**31 and fn(C.c_int(cin), C.c_int(int(cout)), C.c_int(h), C.c_int(w)))
+
+
+def conv3_pack(weight: torch.Tensor, dgrad: bool) -> torch.Tensor:
+    """The filter ``[Cout, Cin, 3, 3]`` (fp32) as the (hi, lo) bf16 planes :func:`conv3_cm` reads, ``[2, 9 * Cin * Cout]``:
+    as it is for the forward product, flipped with the channels swapped for the data gradient.  One launch."""
+    cout, cin, kh, kw = (int(v) for v in weight.shape)
+    if (kh, kw) != (3, 3) or weight.dtype != torch.float32:
+        raise ValueError("conv3_pack: needs an fp32 [Cout, Cin, 3, 3] filter")
+    w = weight.contiguous()
+    planes = torch.empty(2, 9 * cin * cout, dtype=torch.bfloat16, device=w.device)
+    hb.call("atri_conv3_pack", hb.ptr(w), hb.ptr(planes[0]), hb.ptr(planes[1]), hb.i32(cout), hb.i32(cin), hb.i32(1 if dgrad else 0))
+    return planes
+
+
+def conv3_cm(x: torch.Tensor, planes: torch.Tensor, cout: int) -> torch.Tensor:
+    """3x3, padding-1 convolution of channel-major ``x [Cin, B, H, W]`` with a filter packed by :func:`conv3_pack`:
+    ``[cout, B, H, W]``, one workgroup per board, no patch matrix (``conv3_cm_kernel``)."""
+    cin, nb, h, w = (int(v) for v in x.shape)
+    if planes.numel() != 2 * 9 * cin * cout or not conv3_cm_supported(x, cout):
+        raise ValueError("conv3_cm: unsupported input or filter size")
+    out = torch.empty(cout, nb, h, w, dtype=torch.float32, device=x.device)
+    hb.call("atri_conv3_cm", hb.ptr(x), hb.ptr(planes[0]), hb.ptr(planes[1]), hb.ptr(out), hb.i32(cin), hb.i32(cout), hb.i32(nb), hb.i32(h),
+            hb.i32(w))
+    return out
+
+
+def conv_wt(weight: torch.Tensor) -> torch.Tensor:
+    """``[Cin, Cout * kh * kw]``: the spatially flipped filter with input and output channels swapped - the A operand of a
+    convolution's data-gradient GEMM - in one launch (``weight.flip(2, 3).permute(1, 0, 2, 3).reshape(...)`` takes two)."""
+    cout, cin, kh, kw = (int(v) for v in weight.shape)
+    w = weight.contiguous()
+    out = torch.empty(cin, cout * kh * kw, dtype=w.dtype, device=w.device)
+    hb.call("atri_conv_wt", hb.ptr(w), hb.ptr(out), hb.i32(1 if w.dtype == torch.bfloat16 else 0), hb.i32(cout), hb.i32(cin), hb.i32(kh * kw))
     return out
 
 
@@ -382,7 +511,7 @@ def attention_forward(qkv: torch.Tensor, heads: int, p_drop: float) -> tuple[tor
     seq, batch, width = qkv.shape
     ctx = torch.empty(seq, batch, width // 3, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(batch * heads, _lse_pitch(seq), dtype=torch.float32, device=qkv.device)
-    seed = torch.randint(0, 2**62, (1,), dtype=torch.int64, device=qkv.device) if p_drop > 0 else None
+    seed = _drop_seed(qkv.device) if p_drop > 0 else None
     hb.call("atri_attn_fwd", hb.ptr(qkv), hb.i32(1 if qkv.dtype == torch.bfloat16 else 0), hb.ptr(ctx), hb.ptr(lse), hb.ptr(seed),
             hb.i32(seq), hb.i32(batch), hb.i32(heads), hb.f32(p_drop))
     return ctx, lse, seed

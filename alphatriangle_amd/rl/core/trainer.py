@@ -32,6 +32,7 @@ from torch.optim.lr_scheduler import CosineAnnealingLR, StepLR, _LRScheduler
 from ...config.env_config import EnvConfig
 from ...config.train_config import TrainConfig
 from ...models.network import NeuralNetwork
+from ...ops import hip_learner
 from ...ops import hipbind as hb
 from ...ops.losses import LossOutputs, alphazero_loss, c51_two_hot
 from ...ops.optim import FlatParameterSpace, build_optimizer
@@ -194,6 +195,7 @@ class Trainer:
             use_graph if use_graph is not None else getattr(train_config, "COMPILE_MODEL", False)
         ) and self.device.type == "cuda" and self.flat is not None
         self._graphed: GraphedForwardBackward | None = None
+        self._grad_seed: torch.Tensor | None = None
         self.graph_report: dict[str, Any] = {}  # outcome of the capture attempt (node census, validation error)
 
     # ------------------------------------------------------------------ construction
@@ -262,13 +264,20 @@ class Trainer:
             self.flat.release_grads()  # every gradient is written, not accumulated: no zeroing, no per-parameter adds
         else:
             self.optimizer.zero_grad()
-        if self.autocast_bf16:
-            if self.flat is not None:
-                self.flat.refresh_shadow(torch.bfloat16)  # one cast of the flat buffer instead of one per weight
-            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        pooled_seeds = self.device.type == "cuda" and hip_learner.available()
+        if pooled_seeds:
+            hip_learner.begin_step_seeds(self.device)  # one generator launch for all dropout sites of this pass
+        try:
+            if self.autocast_bf16:
+                if self.flat is not None:
+                    self.flat.refresh_shadow(torch.bfloat16)  # one cast of the flat buffer instead of one per weight
+                with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                    policy_logits, value_logits = self.model(tb.grid, tb.other)
+            else:
                 policy_logits, value_logits = self.model(tb.grid, tb.other)
-        else:
-            policy_logits, value_logits = self.model(tb.grid, tb.other)
+        finally:
+            if pooled_seeds:
+                hip_learner.end_step_seeds(self.device)
         out = alphazero_loss(
             policy_logits,
             value_logits,
@@ -281,7 +290,12 @@ class Trainer:
             value_weight=self.train_config.VALUE_LOSS_WEIGHT,
             entropy_weight=self.train_config.ENTROPY_BONUS_WEIGHT,
         )
-        out.total.backward()
+        if self.device.type == "cuda":
+            if self._grad_seed is None:
+                self._grad_seed = torch.ones((), dtype=torch.float32, device=self.device)
+            out.total.backward(self._grad_seed.to(out.total.dtype))  # a kept 1.0 instead of a fill launch per step
+        else:
+            out.total.backward()
         if self.flat is not None:
             self.flat.gather_grads()
         return out

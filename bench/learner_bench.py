@@ -48,7 +48,16 @@ def main() -> None:
         step(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"train_steps_per_sec": args.steps / dt, "samples_per_sec": args.steps * args.batch / dt, "ms_per_step": dt / args.steps * 1e3,
+    graph_ms = None
+    g = trainer._graphed
+    if g is not None and g.ok:  # the captured forward + backward alone, replayed back to back
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            g.graph.replay()
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    print(json.dumps({"graph_only_ms": graph_ms, "graph_kernel_nodes": trainer.graph_report.get("kernel_nodes"), "train_steps_per_sec": args.steps / dt, "samples_per_sec": args.steps * args.batch / dt, "ms_per_step": dt / args.steps * 1e3,
                       "dtype": "fp32" if args.fp32 else "bf16 autocast"}))
 
 

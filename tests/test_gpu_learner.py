@@ -414,6 +414,7 @@ def test_fp32_learner_fast_path_matches_stock_modules(preset, patch_free):
             m.dropout = 0.0
     net_b = copy.deepcopy(net_a)
     net_b.channel_major = False
+    net_b.fused_tail = False  # stock Linear / BatchNorm1d modules on the comparison side
     for m in net_b.modules():
         if isinstance(m, EncoderLayer):
             m.fused_attention = False  # batched-GEMM attention on the comparison side
@@ -612,14 +613,141 @@ def test_gemm3_matches_fp64(m, n, k, a_t, b_t, batch, with_bias):
     assert err < 2e-5
 
 
-def test_gemm3_declines_what_it_cannot_vectorise():
+def test_gemm3_declines_what_it_cannot_run():
     from alphatriangle_amd.ops import hip_learner
 
     dev = torch.device("cuda")
-    assert hip_learner.mm3(torch.randn(32, 9, device=dev), torch.randn(9, 64, device=dev)) is None          # K = 9: not a multiple of 4
-    assert hip_learner.mm3(torch.randn(32, 16, device=dev), torch.randn(16, 30, device=dev)) is None        # N = 30
     assert hip_learner.mm3(torch.randn(32, 16, device=dev).bfloat16(), torch.randn(16, 32, device=dev).bfloat16()) is None
     assert hip_learner.mm3(torch.randn(64, 32, device=dev)[::2, ::2], torch.randn(16, 32, device=dev)) is None  # no unit stride
+
+
+@pytest.mark.parametrize("case", ["odd_everything", "value_head", "shared_layer_slices", "column_block_out", "pairs"])
+def test_gemm3_with_pitches_and_extents_that_are_not_multiples_of_four(case):
+    """Operands whose pitch, extent or base address rules out 16-byte accesses run on the kernel's 8-byte / 4-byte paths:
+    the value head's 51 atoms, the shared layer's 15 390-wide rows (column slices of the weight), a column block of a
+    larger matrix as the output."""
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(53)
+    dev = torch.device("cuda")
+    bias = None
+    out = None
+    if case == "odd_everything":
+        a, b = torch.randn(37, 9, device=dev), torch.randn(9, 31, device=dev)
+        bias = torch.randn(31, device=dev)
+    elif case == "value_head":  # forward, data gradient and weight gradient of Linear(128 -> 51) at batch 256
+        h, w, g = torch.randn(256, 128, device=dev), torch.randn(51, 128, device=dev), torch.randn(256, 51, device=dev)
+        for a, b in ((h, w.t()), (g, w), (g.t(), h)):
+            got = hip_learner.mm3(a, b)
+            ref = a.double() @ b.double()
+            assert got is not None and (got.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+        return
+    elif case == "shared_layer_slices":  # [B, 15360] x column block of W[128, 15390], cut into 60 slices along k
+        x, w = torch.randn(64, 15360, device=dev), torch.randn(128, 15390, device=dev)
+        a = x.view(64, 60, 256).transpose(0, 1)
+        b = w[:, :15360].view(128, 60, 256).permute(1, 2, 0)
+        got = hip_learner.mm3(a, b)
+        assert got is not None
+        ref = x.double() @ w[:, :15360].double().t()
+        err = (got.double().sum(0) - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-5, err
+        small = hip_learner.mm3(torch.randn(64, 30, device=dev), w[:, 15360:].t())
+        assert small is not None and small.shape == (64, 128)
+        return
+    elif case == "column_block_out":  # weight gradient written into its column block of the full matrix
+        g, x = torch.randn(64, 128, device=dev), torch.randn(64, 30, device=dev)
+        full = torch.full((128, 15390), 7.0, device=dev)
+        a, b, out = g.t(), x, full[:, 15360:]
+    else:  # even but not a multiple of four
+        a, b = torch.randn(66, 30, device=dev), torch.randn(30, 54, device=dev)
+    got = hip_learner.mm3(a, b, bias, out=out)
+    assert got is not None
+    torch.cuda.synchronize()
+    ref = a.double() @ b.double() + (bias.double() if bias is not None else 0.0)
+    assert (got.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+    if case == "column_block_out":
+        assert got.data_ptr() == out.data_ptr() and bool((full[:, :15360] == 7.0).all()), "only the column block may be written"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("s,shape,with_bias", [(32, (128, 1152), False), (61, (256, 128), True), (3, (7, 51), True), (1, (5, 3), False)])
+def test_sum_slices_matches_torch(dtype, s, shape, with_bias):
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    parts = torch.randn(s, *shape, device=dev).to(dtype)
+    bias = torch.randn(shape[-1], device=dev) if with_bias else None
+    got = hip_learner.sum_slices(parts, bias)
+    ref = parts.double().sum(0) + (bias.double() if with_bias else 0.0)
+    assert got.dtype == torch.float32 and got.shape == shape
+    assert (got.double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["Identity", "ReLU", "GELU", "Tanh"])
+@pytest.mark.parametrize("b,c", [(256, 128), (37, 50)])
+def test_batchnorm1d_kernels_match_torch(dtype, act, b, c):
+    """One-launch BatchNorm1d (+ activation), forward and backward, against torch's module in fp64."""
+    from alphatriangle_amd.models.model import _Bn1dAct
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(11)
+    dev = torch.device("cuda")
+    bn = torch.nn.BatchNorm1d(c).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    import copy
+
+    ref_bn = copy.deepcopy(bn).double()
+    x = (torch.randn(b, c, device=dev) * 2 + 0.7).to(dtype).requires_grad_(True)
+    xr = x.detach().double().requires_grad_(True)
+    y = _Bn1dAct.apply(x, bn.weight, bn.bias, bn, hip_learner.ACT_IDS[act])
+    yr = getattr(torch.nn, act)()(ref_bn(xr))
+    gy = torch.randn(b, c, device=dev)
+    y.backward(gy.to(dtype))
+    yr.backward(gy.to(dtype).double())
+    tol = 3e-2 if dtype == torch.bfloat16 else 2e-5
+    assert (y.double() - yr).abs().max().item() < tol * max(1.0, yr.abs().max().item())
+    for got, ref, name in ((x.grad, xr.grad, "dx"), (bn.weight.grad, ref_bn.weight.grad, "dgamma"), (bn.bias.grad, ref_bn.bias.grad, "dbeta")):
+        assert (got.double() - ref).abs().max().item() < (10 * tol if dtype == torch.bfloat16 else tol) * max(1.0, ref.abs().max().item()), name
+    assert torch.allclose(bn.running_mean.double(), ref_bn.running_mean, rtol=1e-3, atol=1e-5)
+    assert torch.allclose(bn.running_var.double(), ref_bn.running_var, rtol=1e-3, atol=1e-5)
+    assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cout,cin,k", [(128, 128, 3), (64, 32, 3), (32, 1, 5)])
+def test_flipped_filter_kernel_matches_flip_and_permute(dtype, cout, cin, k):
+    from alphatriangle_amd.ops import hip_learner
+
+    w = torch.randn(cout, cin, k, k, device="cuda").to(dtype)
+    assert torch.equal(hip_learner.conv_wt(w), w.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * k * k))
+
+
+def test_dropout_sites_share_one_generator_launch_per_step():
+    """Inside begin_step_seeds / end_step_seeds every site gets its own element of one draw; outside, its own draw."""
+    from alphatriangle_amd.ops import hip_learner
+
+    dev = torch.device("cuda")
+    torch.manual_seed(1)
+    hip_learner.begin_step_seeds(dev)
+    try:
+        a, b = hip_learner._drop_seed(dev), hip_learner._drop_seed(dev)
+        assert a.data_ptr() + 8 == b.data_ptr() and int(a) != int(b)
+        for _ in range(hip_learner.SEEDS_PER_STEP):  # past the pool: falls back to a draw of its own
+            last = hip_learner._drop_seed(dev)
+        assert last.numel() == 1
+    finally:
+        hip_learner.end_step_seeds(dev)
+    torch.manual_seed(1)
+    hip_learner.begin_step_seeds(dev)
+    again = int(hip_learner._drop_seed(dev))
+    hip_learner.end_step_seeds(dev)
+    assert again == int(a), "torch.manual_seed governs the pool"
+    c = hip_learner._drop_seed(dev)
+    assert c.numel() == 1 and c.data_ptr() != a.data_ptr()
 
 
 def test_fp32_training_trajectory_is_the_same_on_both_gemm_paths():
@@ -703,6 +831,55 @@ def test_patch_free_conv_gemms_match_torch_convolution(cin, cout, batch, h, w):
     print(f"[{cin}->{cout}, {batch} x {h}x{w}] forward {e_f:.2e}, weight gradient {e_w:.2e}, data gradient {e_x:.2e}")
     assert e_f < 2e-5 and e_w < 2e-5 and e_x < 2e-5
     assert d_x is not None or cout % 4 != 0
+
+
+@pytest.mark.parametrize("cin,cout,batch,h,w", [(128, 128, 256, 8, 15), (64, 128, 8, 8, 15), (128, 64, 8, 8, 15), (32, 64, 5, 8, 15),
+                                                (32, 128, 3, 8, 15), (128, 128, 4, 12, 21), (64, 64, 3, 5, 6), (128, 128, 2, 16, 16)])
+def test_direct_conv_kernel_matches_torch_convolution(cin, cout, batch, h, w):
+    """Board-per-workgroup 3x3 convolution (forward with the filter as it is, data gradient with the flipped, transposed
+    filter) against torch's convolution in fp64, next to the GEMM-lowered form it replaces."""
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(61)
+    dev = torch.device("cuda")
+    x = torch.randn(cin, batch, h, w, device=dev)
+    wt = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+    assert hip_learner.conv3_cm_supported(x, cout)
+    got = hip_learner.conv3_cm(x, hip_learner.conv3_pack(wt, False), cout)
+    ref = torch.nn.functional.conv2d(x.permute(1, 0, 2, 3).double(), wt.double(), padding=1).permute(1, 0, 2, 3)
+    err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+    g = torch.randn(cout, batch, h, w, device=dev)
+    if hip_learner.conv3_cm_supported(g, cin):
+        dx = hip_learner.conv3_cm(g, hip_learner.conv3_pack(wt, True), cin)
+        dref = torch.nn.functional.conv_transpose2d(g.permute(1, 0, 2, 3).double(), wt.double(), padding=1).permute(1, 0, 2, 3)
+        derr = (dx.double() - dref).abs().max().item() / dref.abs().max().item()
+    else:
+        derr = 0.0
+    print(f"[{cin}->{cout} batch {batch} {h}x{w}] forward {err:.2e}, data gradient {derr:.2e}")
+    assert err < 2e-5 and derr < 2e-5
+
+
+def test_conv_layer_on_the_direct_kernel_trains_like_the_gemm_lowered_layer():
+    """_ConvGemmCM with DIRECT_CONV on and off: same output, input gradient and weight gradient."""
+    import alphatriangle_amd.models.model as model_mod
+
+    torch.manual_seed(67)
+    dev = torch.device("cuda")
+    x0 = torch.randn(64, 16, 8, 15, device=dev)
+    w0 = torch.randn(128, 64, 3, 3, device=dev) / 24.0
+    gy = torch.randn(128, 16, 8, 15, device=dev)
+    res = []
+    try:
+        for direct in (True, False):
+            model_mod.DIRECT_CONV = direct
+            x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+            y = model_mod._ConvGemmCM.apply(x, w, 1, 1)
+            y.backward(gy)
+            res.append((y.detach(), x.grad, w.grad))
+    finally:
+        model_mod.DIRECT_CONV = True
+    for a, b, name in zip(res[0], res[1], ("y", "dx", "dw")):
+        assert (a - b).abs().max().item() < 3e-5 * b.abs().max().item(), name
 
 
 def _flat_keep_mask(seed: int, n: int, p: float, device) -> torch.Tensor:
