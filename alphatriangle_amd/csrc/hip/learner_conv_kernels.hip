@@ -11,9 +11,14 @@
 //
 // Geometry: MFMA rows are positions (16 per tile, NT tiles cover the board), columns are output channels.  A tap that
 // falls outside the board reads an all-zero LDS row instead (one address select per tile and step, no masking of
-// fragments).  The four waves split the output channels (COT tiles of 16 each); every wave walks all position tiles,
-// so the filter fragments come from global memory (L2-resident, prepacked by conv3_pack_kernel into [tap][ci / 32][co][32]
-// (hi, lo) planes, loaded one step ahead) and the input fragments from LDS.
+// fragments).  Eight waves: four groups of output channels (COT tiles of 16 each) times two halves of the position
+// tiles.  The filter fragments come from global memory (L2-resident, prepacked by conv3_pack_kernel into
+// [tap][ci / 32][co][32] (hi, lo) planes, loaded one step ahead), the input fragments from LDS.  (Four waves that each
+// walk all position tiles read the image twice as often and leave one wave per SIMD: 41 us against the patch-matrix
+// form's 101 us at 128 -> 128 channels and 256 boards.)
+#include <type_traits>
+#include <utility>
+
 #include "common.hpp"
 
 using namespace atrihip;
@@ -50,6 +55,15 @@ __device__ __forceinline__ float4 c3_load_quad(const float* p, int left, int vec
   return v;
 }
 
+template <typename F, int... Is>
+__device__ __forceinline__ void c3_static_for_impl(F& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void c3_static_for(F& f) {  // f(integral_constant<0>) ... f(integral_constant<N - 1>), unrolled
+  c3_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int CIN, int NT>
 struct C3Geom {
   static constexpr int kRows = NT * 16;             // position rows of the LDS image; row kRows is all zeros
@@ -62,13 +76,15 @@ struct C3Geom {
 }  // namespace
 
 template <int CIN, int COT, int NT>
-__global__ __launch_bounds__(256) void conv3_cm_kernel(Conv3CmArgs a) {
+__global__ __launch_bounds__(512) void conv3_cm_kernel(Conv3CmArgs a) {
   using G = C3Geom<CIN, NT>;
   constexpr int COUT = 64 * COT;
   constexpr int KC = CIN / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NTW = NT / 2;  // position tiles per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q4 = lane >> 4;
+  const int wc = wave & 3, t0 = (wave >> 2) * NTW;  // channel group, first position tile
   const int hw = a.h * a.w;
   const long long n0 = (long long)blockIdx.x * hw;
 
@@ -76,7 +92,7 @@ __global__ __launch_bounds__(256) void conv3_cm_kernel(Conv3CmArgs a) {
   {
     constexpr int kPosQuads = G::kRows / 4;
     const float* xb = a.x + n0;
-    for (int blk = tid; blk < (CIN / 4) * kPosQuads; blk += 256) {
+    for (int blk = tid; blk < (CIN / 4) * kPosQuads; blk += 512) {
       const int pq = blk % kPosQuads, cq = blk / kPosQuads;
       const int pos = pq * 4;
       float4 v[4];
@@ -94,17 +110,17 @@ __global__ __launch_bounds__(256) void conv3_cm_kernel(Conv3CmArgs a) {
         *reinterpret_cast<uint2*>(p + G::kPlane) = lo;
       }
     }
-    for (int i = tid; i < G::kRowBytes / 8; i += 256) {  // the zero row of both planes
+    for (int i = tid; i < G::kRowBytes / 8; i += 512) {  // the zero row of both planes
       *reinterpret_cast<uint2*>(smem + G::kRows * G::kRowBytes + i * 8) = make_uint2(0u, 0u);
       *reinterpret_cast<uint2*>(smem + G::kPlane + G::kRows * G::kRowBytes + i * 8) = make_uint2(0u, 0u);
     }
   }
 
   // ---- which taps of this lane's positions lie inside the board (bit tap of valid[t])
-  unsigned valid[NT];
+  unsigned valid[NTW];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int p = t * 16 + l15;
+  for (int t = 0; t < NTW; ++t) {
+    const int p = (t0 + t) * 16 + l15;
     const int y = p / a.w, x = p - y * a.w;
     unsigned m = 0;
     if (p < hw) {
@@ -117,14 +133,14 @@ __global__ __launch_bounds__(256) void conv3_cm_kernel(Conv3CmArgs a) {
     valid[t] = m;
   }
 
-  float4v acc[COT][NT];
+  float4v acc[COT][NTW];
 #pragma unroll
   for (int c = 0; c < COT; ++c)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[c][t] = (float4v){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTW; ++t) acc[c][t] = (float4v){0.f, 0.f, 0.f, 0.f};
 
   // filter fragments of this wave's COT channel tiles for step s = tap * KC + kc: 16 bytes per lane and plane
-  const int co_lane = (wave * COT) * 16 + l15;
+  const int co_lane = (wc * COT) * 16 + l15;
   auto w_offset = [&](int s, int c) { return ((long long)s * COUT + co_lane + c * 16) * 32 + q4 * 8; };
   // KC >= 2 (even): fragments of step s + 1 are loaded while step s is multiplied; the buffer parity is that of kc.
   // KC == 1 (32 input channels, the small early layer): loaded at the start of their step.
@@ -143,52 +159,81 @@ __global__ __launch_bounds__(256) void conv3_cm_kernel(Conv3CmArgs a) {
 #pragma unroll 1
   for (int tap = 0; tap < 9; ++tap) {
     const int shift = (tap / 3 - 1) * a.w + (tap % 3 - 1);
-    int row_off[NT], row_swz[NT];
+    int row_off[NTW], row_swz[NTW];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int row = t * 16 + l15 + shift;
+    for (int t = 0; t < NTW; ++t) {
+      const int row = (t0 + t) * 16 + l15 + shift;
       const bool ok = (valid[t] >> tap) & 1u;
       row_off[t] = ok ? row * G::kRowBytes : kZeroRow;
       row_swz[t] = ok ? (row & G::kSwz) : 0;
     }
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      const int cur = kAhead ? (kc & 1) : 0, nxt = cur ^ 1;
-      const int s = tap * KC + kc;
-      if constexpr (kAhead) {
-        if (s + 1 < 9 * KC) {
-#pragma unroll
-          for (int c = 0; c < COT; ++c) {
-            wh[nxt][c] = *reinterpret_cast<const short8*>(a.whi + w_offset(s + 1, c));
-            wl[nxt][c] = *reinterpret_cast<const short8*>(a.wlo + w_offset(s + 1, c));
-          }
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < COT; ++c) {
-          wh[0][c] = *reinterpret_cast<const short8*>(a.whi + w_offset(s, c));
-          wl[0][c] = *reinterpret_cast<const short8*>(a.wlo + w_offset(s, c));
-        }
-      }
+    // One tap = KC * NG units of TG position tiles at one 32-channel step.  The fragments of unit u + 1 are read from LDS
+    // while unit u is multiplied, and a unit's MFMAs go pass by pass over TG * COT independent accumulators (three
+    // chained passes on one accumulator would wait for each other).
+    constexpr int TG = 4, NG = NTW / TG, U = KC * NG;
+    short8 xh[2][TG], xl[2][TG];
+    auto load_unit = [&](auto UC, auto BUF) {
+      constexpr int u = decltype(UC)::value, buf = decltype(BUF)::value;
+      constexpr int kc = u / NG, g = u % NG;
       const int slot = kc * 4 + q4;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int i = 0; i < TG; ++i) {
+        const int t = g * TG + i;
         const unsigned char* p = smem + row_off[t] + ((slot ^ row_swz[t]) << 4);
-        const short8 xh = *reinterpret_cast<const short8*>(p);
-        const short8 xl = *reinterpret_cast<const short8*>(p + G::kPlane);
-#pragma unroll
-        for (int c = 0; c < COT; ++c) acc[c][t] = mfma_split(xh, xl, wh[cur][c], wl[cur][c], acc[c][t]);
+        xh[buf][i] = *reinterpret_cast<const short8*>(p);
+        xl[buf][i] = *reinterpret_cast<const short8*>(p + G::kPlane);
       }
-    }
+    };
+    load_unit(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    auto unit = [&](auto UC) {
+      constexpr int u = decltype(UC)::value;
+      constexpr int kc = u / NG, g = u % NG, buf = u & 1;
+      constexpr int cur = kAhead ? (kc & 1) : 0, nxt = cur ^ 1;
+      if constexpr (g == 0) {  // filter fragments: one 32-channel step ahead (or for this step when KC == 1)
+        const int s = tap * KC + kc;
+        if constexpr (kAhead) {
+          if (s + 1 < 9 * KC) {
+#pragma unroll
+            for (int c = 0; c < COT; ++c) {
+              wh[nxt][c] = *reinterpret_cast<const short8*>(a.whi + w_offset(s + 1, c));
+              wl[nxt][c] = *reinterpret_cast<const short8*>(a.wlo + w_offset(s + 1, c));
+            }
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < COT; ++c) {
+            wh[0][c] = *reinterpret_cast<const short8*>(a.whi + w_offset(s, c));
+            wl[0][c] = *reinterpret_cast<const short8*>(a.wlo + w_offset(s, c));
+          }
+        }
+      }
+      if constexpr (u + 1 < U) load_unit(std::integral_constant<int, u + 1>{}, std::integral_constant<int, (u + 1) & 1>{});
+#pragma unroll
+      for (int i = 0; i < TG; ++i)
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+          acc[c][g * TG + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[buf][i], wh[cur][c], acc[c][g * TG + i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TG; ++i)
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+          acc[c][g * TG + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[buf][i], wl[cur][c], acc[c][g * TG + i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TG; ++i)
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+          acc[c][g * TG + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[buf][i], wh[cur][c], acc[c][g * TG + i], 0, 0, 0);
+    };
+    c3_static_for<U>(unit);
   }
 
-  // acc[c][t][e] = out(co = (wave * COT + c) * 16 + l15, position t * 16 + 4 q4 + e)
+  // acc[c][t][e] = out(co = (wc * COT + c) * 16 + l15, position (t0 + t) * 16 + 4 q4 + e)
 #pragma unroll
   for (int c = 0; c < COT; ++c) {
     float* orow = a.out + (long long)(co_lane + c * 16) * a.n_total + n0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int pos = t * 16 + q4 * 4;
+    for (int t = 0; t < NTW; ++t) {
+      const int pos = (t0 + t) * 16 + q4 * 4;
       const int left = hw - pos;
       if (left <= 0) continue;
       if (a.vec == 4) {
@@ -220,6 +265,188 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict
   lo[i] = float_to_bf16(v - bf16_to_float(h));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution without a patch matrix:
+//
+//   dW[co][ci][dy, dx] = sum over boards and positions q of g[co][q] * x[ci][q + dy * P + dx]
+//
+// in PADDED board coordinates (pitch P = W + 1 rounded up to a multiple of 8, one zero row above and below): every
+// position outside the board holds a zero in the staged copy of x, and g is zero in the padding columns, so no product
+// needs a mask.  The reduction index of the MFMA is the position, contiguous for both operands as they lie in memory
+// (no transposition).  A tap shifts the x operand by dy * P + dx positions; with P a multiple of 8 only dx moves a
+// 16-byte LDS read off its alignment, so x is staged three times, shifted by -1, 0 and +1 positions, and every read is
+// aligned.  One workgroup = (a slice of the boards) x (32 input channels) x all output channels x 9 taps; its eight waves
+// are 4 groups of output-channel tiles x 2 input-channel tiles, 9 * COT accumulator tiles each.  The slices are added by
+// conv3_wgrad_reduce_kernel, which also turns [tap][co][ci] into the parameter's [co][ci][tap].
+struct Conv3WgArgs {
+  const float* g;    // [cout][n_total]
+  const float* x;    // [cin][n_total]
+  float* part;       // [slices][9][cout][cin]
+  long long n_total;
+  int cin, boards, boards_per_wg, h, w, P, ksteps;
+  int g_stride, x_stride;  // bytes per LDS row (one plane), padded against bank conflicts
+};
+
+namespace {
+__device__ __forceinline__ void c3_split8(const float (&v)[8], uint4& hi, uint4& lo) {
+  uint2 h0, l0, h1, l1;
+  c3_split4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+  c3_split4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+  hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+}  // namespace
+
+template <int COT>
+__global__ __launch_bounds__(512) void conv3_wgrad_kernel(Conv3WgArgs a) {
+  constexpr int COUT = 64 * COT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int cg = wave & 3, half = wave >> 2;
+  const int hw = a.h * a.w, P = a.P;
+  const int K32 = a.ksteps * 32;      // padded positions of one board the reduction runs over (rows 1 .. H of the padded image)
+  const int Lq = K32 + 2 * P;         // staged x positions: one padded row before and after
+  unsigned char* g_hi = smem;
+  unsigned char* g_lo = g_hi + COUT * a.g_stride;
+  unsigned char* x_hi = g_lo + COUT * a.g_stride;
+  unsigned char* x_lo = x_hi + 3 * 32 * a.x_stride;
+  const int ci0 = blockIdx.y * 32;
+
+  float4v acc[9][COT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < COT; ++c) acc[t][c] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+  for (int bi = 0; bi < a.boards_per_wg; ++bi) {
+    const int board = blockIdx.x * a.boards_per_wg + bi;
+    if (board >= a.boards) break;  // uniform over the workgroup
+    const long long n0 = (long long)board * hw;
+    __syncthreads();  // the previous board's fragments have been read
+    // g -> [co][k] planes, k = y * P + c with board column c - 1 (zeros in the padding columns and beyond the last row)
+    for (int o = tid; o < COUT * (K32 / 8); o += 512) {
+      const int co = o / (K32 / 8), k8 = (o - co * (K32 / 8)) * 8;
+      const int y = k8 / P, c0 = k8 - y * P;
+      const float* src = a.g + (long long)co * a.n_total + n0 + y * a.w + (c0 - 1);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int xb = c0 + e - 1;
+        v[e] = (y < a.h && xb >= 0 && xb < a.w) ? src[e] : 0.f;
+      }
+      uint4 hi, lo;
+      c3_split8(v, hi, lo);
+      *reinterpret_cast<uint4*>(g_hi + co * a.g_stride + k8 * 2) = hi;
+      *reinterpret_cast<uint4*>(g_lo + co * a.g_stride + k8 * 2) = lo;
+    }
+    // x -> three copies [d][ci][j], copy d holding the padded image shifted by d - 1 positions
+    for (int o = tid; o < 32 * (Lq / 8); o += 512) {
+      const int ci = o / (Lq / 8), j8 = (o - ci * (Lq / 8)) * 8;
+      const float* src = a.x + (long long)(ci0 + ci) * a.n_total + n0;
+      float v[10];  // padded positions j8 - 1 .. j8 + 8
+#pragma unroll
+      for (int e = 0; e < 10; ++e) {
+        const int q = j8 - 1 + e;
+        const int r = q >= 0 ? q / P : -1;
+        const int yy = r - 1, xb = q - r * P - 1;
+        const bool ok = q >= 0 && yy >= 0 && yy < a.h && xb >= 0 && xb < a.w;
+        v[e] = ok ? src[yy * a.w + xb] : 0.f;
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float f[8] = {v[d], v[d + 1], v[d + 2], v[d + 3], v[d + 4], v[d + 5], v[d + 6], v[d + 7]};
+        uint4 hi, lo;
+        c3_split8(f, hi, lo);
+        *reinterpret_cast<uint4*>(x_hi + (d * 32 + ci) * a.x_stride + j8 * 2) = hi;
+        *reinterpret_cast<uint4*>(x_lo + (d * 32 + ci) * a.x_stride + j8 * 2) = lo;
+      }
+    }
+    __syncthreads();
+    for (int ks = 0; ks < a.ksteps; ++ks) {
+      const int kb = ks * 32 + q4 * 8;
+      short8 gh[COT], gl[COT];
+#pragma unroll
+      for (int c = 0; c < COT; ++c) {
+        const int off = ((cg * COT + c) * 16 + l15) * a.g_stride + kb * 2;
+        gh[c] = *reinterpret_cast<const short8*>(g_hi + off);
+        gl[c] = *reinterpret_cast<const short8*>(g_lo + off);
+      }
+      short8 xh[9], xl[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, d = t % 3;
+        const int off = (d * 32 + half * 16 + l15) * a.x_stride + (kb + P + dy * P) * 2;
+        xh[t] = *reinterpret_cast<const short8*>(x_hi + off);
+        xl[t] = *reinterpret_cast<const short8*>(x_lo + off);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[t], gh[c], acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[t], gl[c], acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[t], gh[c], acc[t][c], 0, 0, 0);
+    }
+  }
+  // acc[t][c][e] = dW(tap t, co = (cg * COT + c) * 16 + l15, ci = ci0 + half * 16 + 4 q4 + e) of this slice
+  float* part = a.part + (long long)blockIdx.x * 9 * COUT * a.cin;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+      const int co = (cg * COT + c) * 16 + l15;
+      *reinterpret_cast<float4*>(part + ((long long)t * COUT + co) * a.cin + ci0 + half * 16 + q4 * 4) =
+          make_float4(acc[t][c][0], acc[t][c][1], acc[t][c][2], acc[t][c][3]);
+    }
+}
+
+// dW[co][ci][tap] = sum over the slices of part[s][tap][co][ci].  64 quads of ci per workgroup, the four waves take every
+// fourth slice each.
+__global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int cout,
+                                                                 int cin) {
+  __shared__ float4 sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long F = 9LL * cout * cin;
+  const long long f = ((long long)blockIdx.x * 64 + lane) * 4;
+  float4 acc4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (f < F) {
+    const float* p = part + f;
+    int s = wave;
+    for (; s + 12 < S; s += 16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (long long)(s + 4 * i) * F);
+        acc4[i].x += v.x; acc4[i].y += v.y; acc4[i].z += v.z; acc4[i].w += v.w;
+      }
+    }
+    for (; s < S; s += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (long long)s * F);
+      acc4[0].x += v.x; acc4[0].y += v.y; acc4[0].z += v.z; acc4[0].w += v.w;
+    }
+  }
+  sm[wave][lane] = make_float4((acc4[0].x + acc4[1].x) + (acc4[2].x + acc4[3].x), (acc4[0].y + acc4[1].y) + (acc4[2].y + acc4[3].y),
+                               (acc4[0].z + acc4[1].z) + (acc4[2].z + acc4[3].z), (acc4[0].w + acc4[1].w) + (acc4[2].w + acc4[3].w));
+  __syncthreads();
+  if (wave == 0 && f < F) {
+    float4 t = sm[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      t.x += sm[w][lane].x; t.y += sm[w][lane].y; t.z += sm[w][lane].z; t.w += sm[w][lane].w;
+    }
+    const int ci = (int)(f % cin), co = (int)((f / cin) % cout), tap = (int)(f / ((long long)cin * cout));
+    float* o = dw + ((long long)co * cin + ci) * 9 + tap;
+    o[0] = t.x; o[9] = t.y; o[18] = t.z; o[27] = t.w;
+  }
+}
+
 namespace {
 template <int CIN, int COT, int NT>
 int launch_conv3(const Conv3CmArgs& a, int boards, hipStream_t s) {
@@ -229,7 +456,7 @@ int launch_conv3(const Conv3CmArgs& a, int boards, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv3_cm_kernel<CIN, COT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds);
     attr = true;
   }
-  hipLaunchKernelGGL((conv3_cm_kernel<CIN, COT, NT>), dim3(boards), dim3(256), G::kLds, s, a);
+  hipLaunchKernelGGL((conv3_cm_kernel<CIN, COT, NT>), dim3(boards), dim3(512), G::kLds, s, a);
   return hip_err(hipGetLastError());
 }
 }  // namespace
@@ -282,6 +509,75 @@ int atri_conv3_cm(const float* x, const unsigned short* whi, const unsigned shor
     if (cin == 32 && cout == 64) return launch_conv3<32, 1, 8>(a, boards, s);
   }
   return (int)hipErrorInvalidValue;
+}
+
+// Sizes of the weight-gradient kernel for a board: pitch, steps, LDS bytes; 0 when the board does not fit (then the caller
+// multiplies with the patch matrix instead).
+static int c3_wgrad_geometry(int cout, int h, int w, int* P, int* ksteps, int* g_stride, int* x_stride) {
+  *P = (w + 1 + 7) / 8 * 8;
+  const int K32 = (h * *P + 31) / 32 * 32;
+  *ksteps = K32 / 32;
+  const int Lq = K32 + 2 * *P;
+  // row pitches in bytes: a multiple of 16 that is 16 mod 256 apart from a multiple of 256 spreads 16 rows over all banks
+  auto pitch = [](int bytes) {
+    int p = (bytes + 15) / 16 * 16;
+    while ((p / 4) % 64 != 4 && (p / 4) % 64 != 20 && (p / 4) % 64 != 36 && (p / 4) % 64 != 52) p += 16;
+    return p;
+  };
+  *g_stride = pitch(K32 * 2);
+  *x_stride = pitch(Lq * 2);
+  return 2 * cout * *g_stride + 2 * 3 * 32 * *x_stride;
+}
+
+// 1 when atri_conv3_wgrad handles these sizes.
+int atri_conv3_wgrad_supported(int cin, int cout, int h, int w) {
+  if (h < 1 || w < 1 || (cin & 31) || cin < 32 || (cout != 64 && cout != 128)) return 0;
+  int P, ks, gs, xs;
+  return c3_wgrad_geometry(cout, h, w, &P, &ks, &gs, &xs) <= 160 * 1024;
+}
+
+// Number of board slices (= partial results) atri_conv3_wgrad uses for this problem.
+int atri_conv3_wgrad_slices(int cin, int boards) {
+  const int blocks = cin / 32;
+  int s = 256 / (blocks > 0 ? blocks : 1);
+  if (s < 1) s = 1;
+  if (s > boards) s = boards;
+  const int per = (boards + s - 1) / s;
+  return (boards + per - 1) / per;
+}
+
+// dw[cout][cin][3][3] = weight gradient of the 3x3, padding-1 convolution: g [cout][boards*h*w], x [cin][boards*h*w] (fp32,
+// channel-major); part: atri_conv3_wgrad_slices(cin, boards) * 9 * cout * cin floats of scratch.
+int atri_conv3_wgrad(const float* g, const float* x, float* part, float* dw, int cin, int cout, int boards, int h, int w,
+                     hipStream_t s) {
+  if (boards <= 0) return (int)hipErrorInvalidValue;
+  if (!atri_conv3_wgrad_supported(cin, cout, h, w)) return (int)hipErrorInvalidValue;
+  if (((uintptr_t)part | (uintptr_t)dw) & 15) return (int)hipErrorInvalidValue;
+  Conv3WgArgs a{};
+  a.g = g; a.x = x; a.part = part; a.n_total = (long long)boards * h * w;
+  a.cin = cin; a.boards = boards; a.h = h; a.w = w;
+  const int lds = c3_wgrad_geometry(cout, h, w, &a.P, &a.ksteps, &a.g_stride, &a.x_stride);
+  const int slices = atri_conv3_wgrad_slices(cin, boards);
+  a.boards_per_wg = (boards + slices - 1) / slices;
+  const dim3 grid(slices, cin / 32);
+  if (cout == 128) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)conv3_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv3_wgrad_kernel<2>, grid, dim3(512), lds, s, a);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)conv3_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv3_wgrad_kernel<1>, grid, dim3(512), lds, s, a);
+  }
+  const long long F = 9LL * cout * cin;
+  hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3((unsigned)((F / 4 + 63) / 64)), dim3(256), 0, s, part, dw, slices, cout, cin);
+  return hip_err(hipGetLastError());
 }
 
 }  // extern "C"

@@ -54,8 +54,9 @@ FP32_GEMM_ON_BF16_CORES = True
 PATCH_FREE_CONV = False
 # 3x3 / padding-1 convolutions of the fp32 path (forward and data gradient) on the board-per-workgroup kernel
 # (ops.hip_learner.conv3_cm): the input is staged once into LDS and the nine taps are shifted reads of it, where the
-# GEMM-lowered form writes and reads a nine times larger patch matrix.  The weight gradient still multiplies with the
-# patch matrix, which the backward pass then builds itself.  False restores the GEMM-lowered products (A/B runs, tests).
+# GEMM-lowered form writes and reads a nine times larger patch matrix; the weight gradient comes from its own kernel
+# (ops.hip_learner.conv3_wgrad_cm) over the same unpadded operands.  False restores the GEMM-lowered products (A/B runs,
+# tests).
 DIRECT_CONV = True
 
 
@@ -233,9 +234,14 @@ class _ConvGemmCM(torch.autograd.Function):
         g = grad_out.contiguous()
         d_x = d_w = None
         direct = getattr(ctx, "direct", False)
+        wgrad_done = False
         if direct and ctx.needs_input_grad[1]:
-            cols = hip_learner.patch_matrix_cm(cols, kh, kw, ph, pw)  # the weight gradient's operand, built here instead of kept
-        if ctx.needs_input_grad[1]:
+            if hip_learner.conv3_wgrad_supported(g, cols):
+                d_w = hip_learner.conv3_wgrad_cm(g, cols)
+                wgrad_done = True
+            else:
+                cols = hip_learner.patch_matrix_cm(cols, kh, kw, ph, pw)  # the split-K GEMM's operand, built here instead of kept
+        if ctx.needs_input_grad[1] and not wgrad_done:
             n = b * h * w if ctx.implicit else cols.shape[1]
             g2 = g.view(cout, n)
             s = _split_count(n)

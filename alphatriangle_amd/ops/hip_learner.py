@@ -439,6 +439,34 @@ def conv3_cm(x: torch.Tensor, planes: torch.Tensor, cout: int) -> torch.Tensor:
     return out
 
 
+def conv3_wgrad_supported(g: torch.Tensor, x: torch.Tensor) -> bool:
+    """True when :func:`conv3_wgrad_cm` handles channel-major ``g [Cout, B, H, W]`` and ``x [Cin, B, H, W]`` (fp32, contiguous)."""
+    if not (g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.dim() == 4 and x.dim() == 4 and g.shape[1:] == x.shape[1:]
+            and g.is_contiguous() and x.is_contiguous() and available()):
+        return False
+    fn = getattr(hb.lib(), "atri_conv3_wgrad_supported")
+    fn.restype = C.c_int
+    cin, nb, h, w = (int(v) for v in x.shape)
+    return bool(nb >= 1 and max(g.numel(), x.numel()) < 2**31 and fn(C.c_int(cin), C.c_int(int(g.shape[0])), C.c_int(h), C.c_int(w)))
+
+
+def conv3_wgrad_cm(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Weight gradient ``[Cout, Cin, 3, 3]`` of a 3x3, padding-1 convolution from the output gradient ``g [Cout, B, H, W]`` and the
+    input ``x [Cin, B, H, W]`` (channel-major fp32) without a patch matrix: ``conv3_wgrad_kernel`` over slices of the boards
+    plus one reduction launch."""
+    if not conv3_wgrad_supported(g, x):
+        raise ValueError("conv3_wgrad_cm: unsupported operands")
+    cin, nb, h, w = (int(v) for v in x.shape)
+    cout = int(g.shape[0])
+    fn = getattr(hb.lib(), "atri_conv3_wgrad_slices")
+    fn.restype = C.c_int
+    slices = int(fn(C.c_int(cin), C.c_int(nb)))
+    part = torch.empty(slices * 9 * cout * cin, dtype=torch.float32, device=x.device)
+    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
+    hb.call("atri_conv3_wgrad", hb.ptr(g), hb.ptr(x), hb.ptr(part), hb.ptr(dw), hb.i32(cin), hb.i32(cout), hb.i32(nb), hb.i32(h), hb.i32(w))
+    return dw
+
+
 def conv_wt(weight: torch.Tensor) -> torch.Tensor:
     """``[Cin, Cout * kh * kw]``: the spatially flipped filter with input and output channels swapped - the A operand of a
     convolution's data-gradient GEMM - in one launch (``weight.flip(2, 3).permute(1, 0, 2, 3).reshape(...)`` takes two)."""

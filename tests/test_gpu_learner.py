@@ -859,6 +859,26 @@ def test_direct_conv_kernel_matches_torch_convolution(cin, cout, batch, h, w):
     assert err < 2e-5 and derr < 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,batch,h,w", [(128, 128, 256, 8, 15), (64, 128, 7, 8, 15), (128, 64, 5, 8, 15), (32, 64, 300, 8, 15),
+                                                (32, 128, 3, 5, 6), (64, 64, 2, 7, 9)])
+def test_direct_conv_weight_gradient_matches_torch(cin, cout, batch, h, w):
+    """Weight gradient from the padded-board kernel (three shifted copies of the input in LDS, slices of the boards added
+    by a reduction launch) against autograd in fp64."""
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(71)
+    dev = torch.device("cuda")
+    x = torch.randn(cin, batch, h, w, device=dev)
+    g = torch.randn(cout, batch, h, w, device=dev)
+    assert hip_learner.conv3_wgrad_supported(g, x)
+    got = hip_learner.conv3_wgrad_cm(g, x)
+    wt = torch.zeros(cout, cin, 3, 3, device=dev, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.permute(1, 0, 2, 3).double(), wt, padding=1).backward(g.permute(1, 0, 2, 3).double())
+    err = (got.double() - wt.grad).abs().max().item() / wt.grad.abs().max().item()
+    print(f"[{cin}->{cout} batch {batch} {h}x{w}] weight gradient {err:.2e}")
+    assert err < 2e-5
+
+
 def test_conv_layer_on_the_direct_kernel_trains_like_the_gemm_lowered_layer():
     """_ConvGemmCM with DIRECT_CONV on and off: same output, input gradient and weight gradient."""
     import alphatriangle_amd.models.model as model_mod
