@@ -259,26 +259,32 @@ __device__ __forceinline__ float4v act4h(float4v v, int act) {
   return v;
 }
 
-// acc[n] += W x for the 128-deep layer whose packed (hi | lo) fragments start at w; tile_h / tile_l are this lane's rows
-__device__ __forceinline__ void gemm128_split(const unsigned short* __restrict__ w, long long lo_off, size_t frag_index,
-                                              const unsigned char* __restrict__ tile_h, const unsigned char* __restrict__ tile_l,
-                                              float4v (&acc)[2]) {
+// The sixteen (hi, lo) weight fragments of this lane for one 128-deep, 32-channel-per-wave layer block, and the product
+// with the LDS tile rows of this lane.  Separate, so that the loads of the next layer's weights can be issued before the
+// current layer is multiplied: the kernel is a chain of five small layers, each of which would otherwise start with a
+// round trip to L2.
+struct W128 {
+  short8 h[4][2], l[4][2];
+};
+__device__ __forceinline__ void load_w128(W128& f, const unsigned short* __restrict__ w, long long lo_off, size_t frag_index) {
   const short8* wph = reinterpret_cast<const short8*>(w) + frag_index;
   const short8* wpl = reinterpret_cast<const short8*>(w + lo_off) + frag_index;
-  short8 wh[4][2], wl[4][2];
 #pragma unroll
   for (int kc = 0; kc < 4; ++kc) {
-    wh[kc][0] = wph[kc * 512];
-    wh[kc][1] = wph[kc * 512 + 64];
-    wl[kc][0] = wpl[kc * 512];
-    wl[kc][1] = wpl[kc * 512 + 64];
+    f.h[kc][0] = wph[kc * 512];
+    f.h[kc][1] = wph[kc * 512 + 64];
+    f.l[kc][0] = wpl[kc * 512];
+    f.l[kc][1] = wpl[kc * 512 + 64];
   }
+}
+__device__ __forceinline__ void mma_w128(const W128& f, const unsigned char* __restrict__ tile_h, const unsigned char* __restrict__ tile_l,
+                                         float4v (&acc)[2]) {
 #pragma unroll
   for (int kc = 0; kc < 4; ++kc) {
     const short8 xh = *reinterpret_cast<const short8*>(tile_h + kc * 64);
     const short8 xl = *reinterpret_cast<const short8*>(tile_l + kc * 64);
-    acc[0] = mma_split3(wh[kc][0], wl[kc][0], xh, xl, acc[0]);
-    acc[1] = mma_split3(wh[kc][1], wl[kc][1], xh, xl, acc[1]);
+    acc[0] = mma_split3(f.h[kc][0], f.l[kc][0], xh, xl, acc[0]);
+    acc[1] = mma_split3(f.h[kc][1], f.l[kc][1], xh, xl, acc[1]);
   }
 }
 }  // namespace
@@ -294,6 +300,12 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
   const int nB = live_rows(a.live, a.B);
   if (b0 >= nB) return;  // whole workgroup, before any barrier
 
+  // weights of both hidden layers: requested now, used after the slab sums
+  const size_t frag = (size_t)wave * 128 + lane;
+  W128 w_p1, w_v1;
+  load_w128(w_p1, a.wp1, a.lo_p1, frag);
+  load_w128(w_v1, a.wv1, a.lo_v1, frag);
+
   // ---- shared FC: sum the split-K slabs, bias, activation (fp32) -> s_tile planes (thread = sample, 8 channels) ----
   {
     const int r = tid >> 4, n0 = (tid & 15) * 8;
@@ -308,8 +320,25 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
       v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
       const int n_slabs = fc_plan(nB, a.fc_rows_per_block, a.fc_row_blocks, a.SK, a.fc_steps_per_split, a.fc_total_steps,
                                   a.fc_max_splits).splits;
-      for (int s = 0; s < n_slabs; ++s) {
-        const float4* sp = reinterpret_cast<const float4*>(a.slabs + ((size_t)s * a.B + b) * 128 + n0);
+      const size_t slab_pitch = (size_t)a.B * 128;
+      const float* sp0 = a.slabs + (size_t)b * 128 + n0;
+      int s = 0;
+      for (; s + 3 < n_slabs; s += 4) {  // four slabs per round trip (a thin wave has up to sixteen)
+        float4 p[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4* sp = reinterpret_cast<const float4*>(sp0 + (size_t)(s + i) * slab_pitch);
+          p[i][0] = sp[0];
+          p[i][1] = sp[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[0] += p[i][0].x; v[1] += p[i][0].y; v[2] += p[i][0].z; v[3] += p[i][0].w;
+          v[4] += p[i][1].x; v[5] += p[i][1].y; v[6] += p[i][1].z; v[7] += p[i][1].w;
+        }
+      }
+      for (; s < n_slabs; ++s) {
+        const float4* sp = reinterpret_cast<const float4*>(sp0 + (size_t)s * slab_pitch);
         const float4 p0 = sp[0], p1 = sp[1];
         v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
         v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
@@ -332,11 +361,15 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
   // ---- hidden layers of both heads: wave = 32 output channels, lane ends with 8 consecutive channels of sample l15 ----
   const int lane_off = l15 * kHeadPitchS + q4 * 16;
   const int ch = wave * 32 + q4 * 8;
-  const size_t frag = (size_t)wave * 128 + lane;
+  // weights of the value logits and of the first policy block: requested before the hidden layers are multiplied
+  W128 w_v2, w_p2;
+  const bool value_wave = wave * 32 < a.atoms_store;
+  load_w128(w_v2, a.wv2, a.lo_v2, value_wave ? frag : (size_t)lane);
+  load_w128(w_p2, a.wp2, a.lo_p2, frag);
 #pragma unroll
   for (int head = 0; head < 2; ++head) {
     float4v acc[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
-    gemm128_split(head == 0 ? a.wp1 : a.wv1, head == 0 ? a.lo_p1 : a.lo_v1, frag, s_tile[0] + lane_off, s_tile[1] + lane_off, acc);
+    mma_w128(head == 0 ? w_p1 : w_v1, s_tile[0] + lane_off, s_tile[1] + lane_off, acc);
     const float* bias = (head == 0 ? a.bp1 : a.bv1) + ch;
     float4v lo = acc[0], hi = acc[1];
 #pragma unroll
@@ -358,9 +391,9 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
 
   // ---- value logits (one 128-channel block; waves beyond the atom count idle) -> LDS + memory ----
   const int b = b0 + l15;
-  if (wave * 32 < a.atoms_store) {
+  if (value_wave) {
     float4v acc[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
-    gemm128_split(a.wv2, a.lo_v2, frag, v_tile[0] + lane_off, v_tile[1] + lane_off, acc);
+    mma_w128(w_v2, v_tile[0] + lane_off, v_tile[1] + lane_off, acc);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
 #pragma unroll
@@ -376,7 +409,9 @@ __global__ __launch_bounds__(256) void heads_split_kernel(SplitHeadsArgs a) {
   for (int nb = 0; nb < a.nbp; ++nb) {
     if (nb * 128 + wave * 32 >= a.a_store) break;  // wave-uniform
     float4v acc[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
-    gemm128_split(a.wp2, a.lo_p2, ((size_t)nb * 16 + wave) * 128 + lane, p_tile[0] + lane_off, p_tile[1] + lane_off, acc);
+    const W128 w_now = w_p2;
+    if (nb + 1 < a.nbp) load_w128(w_p2, a.wp2, a.lo_p2, ((size_t)(nb + 1) * 16 + wave) * 128 + lane);  // next block's weights
+    mma_w128(w_now, p_tile[0] + lane_off, p_tile[1] + lane_off, acc);
     const int c0 = nb * 128 + ch;
     if (b < nB && c0 < a.a_store) {
       const float4* bp = reinterpret_cast<const float4*>(a.bp2 + c0);
