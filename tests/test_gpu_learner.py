@@ -726,6 +726,55 @@ def test_flipped_filter_kernel_matches_flip_and_permute(dtype, cout, cin, k):
     assert torch.equal(hip_learner.conv_wt(w), w.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * k * k))
 
 
+@pytest.mark.parametrize("variant", ["no_bn_gelu", "deep_shared", "no_hidden_heads", "odd_widths"])
+def test_learner_tail_kernels_follow_unusual_head_configurations(variant):
+    """The in-tree shared layer / heads path against the stock modules for head stacks the default network does not have:
+    no BatchNorm, other activations, several or no hidden layers, widths and feature counts that are not multiples of
+    four (5x6 board: 30 cells x 32 channels + 7 other features)."""
+    import copy
+
+    from alphatriangle_amd.models.model import AlphaTriangleNet
+
+    torch.manual_seed(83)
+    dev = torch.device("cuda")
+    env = EnvConfig(ROWS=5, COLS=6, PLAYABLE_RANGE_PER_ROW=[(0, 6)] * 5, NUM_SHAPE_SLOTS=2)
+    kw = dict(CONV_FILTERS=[32], CONV_KERNEL_SIZES=[3], CONV_STRIDES=[1], CONV_PADDING=[1], NUM_RESIDUAL_BLOCKS=0,
+              RESIDUAL_BLOCK_FILTERS=32, USE_TRANSFORMER=False, TRANSFORMER_LAYERS=0, OTHER_NN_INPUT_FEATURES_DIM=7)
+    if variant == "no_bn_gelu":
+        mc = ModelConfig(**kw, USE_BATCH_NORM=False, ACTIVATION_FUNCTION="GELU", FC_DIMS_SHARED=[64], POLICY_HEAD_DIMS=[48], VALUE_HEAD_DIMS=[40])
+    elif variant == "deep_shared":
+        mc = ModelConfig(**kw, FC_DIMS_SHARED=[96, 64, 32], POLICY_HEAD_DIMS=[64, 64], VALUE_HEAD_DIMS=[32], ACTIVATION_FUNCTION="SiLU")
+    elif variant == "no_hidden_heads":
+        mc = ModelConfig(**kw, FC_DIMS_SHARED=[128], POLICY_HEAD_DIMS=[], VALUE_HEAD_DIMS=[], NUM_VALUE_ATOMS=21)
+    else:
+        mc = ModelConfig(**kw, FC_DIMS_SHARED=[50], POLICY_HEAD_DIMS=[34], VALUE_HEAD_DIMS=[18], NUM_VALUE_ATOMS=11, ACTIVATION_FUNCTION="Tanh")
+    net_a = AlphaTriangleNet(mc, env).to(dev).train()
+    net_b = copy.deepcopy(net_a)
+    net_b.fused_tail = False
+    net_c = copy.deepcopy(net_b).double()
+    B = 48
+    grid = torch.randint(-1, 2, (B, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(B, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    res = []
+    for net, dt in ((net_a, torch.float32), (net_b, torch.float32), (net_c, torch.float64)):
+        pl, vl = net(grid.to(dt), other.to(dt))
+        (pl.square().mean() + vl.square().mean()).backward()
+        res.append((pl.detach().double(), vl.detach().double(), {n: p.grad.double() for n, p in net.named_parameters()}))
+    torch.cuda.synchronize()
+    assert res[0][0].shape == res[2][0].shape and res[0][1].shape == res[2][1].shape
+    for k in (0, 1):
+        assert (res[0][k] - res[2][k]).abs().max().item() < 2e-4 * max(1.0, res[2][k].abs().max().item())
+    top = max(g.abs().max().item() for g in res[2][2].values())
+    for name, g in res[2][2].items():
+        scale = max(g.abs().max().item(), 1e-3 * top)
+        err_fast = (res[0][2][name] - g).abs().max().item() / scale
+        err_lib = (res[1][2][name] - g).abs().max().item() / scale
+        assert err_fast < max(5e-3, 50 * err_lib), (name, err_fast, err_lib)
+    for (name, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        if "running" in name:
+            assert torch.allclose(ba, bb, rtol=1e-3, atol=1e-5), name
+
+
 def test_dropout_sites_share_one_generator_launch_per_step():
     """Inside begin_step_seeds / end_step_seeds every site gets its own element of one draw; outside, its own draw."""
     from alphatriangle_amd.ops import hip_learner
