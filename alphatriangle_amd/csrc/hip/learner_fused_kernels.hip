@@ -358,6 +358,68 @@ __global__ __launch_bounds__(256) void act_dropout_kernel(const T* __restrict__ 
   store8<T>(out + i0, v);
 }
 
+// Channel-major body output -> encoder tokens, with the positional table and its dropout in the same pass:
+//   forward : tokens[p][b][c] = dropout(x[c][b * HW + p] + pe[p][c])        x: [D][B * HW] (T: fp32 or bf16), tokens: fp32
+//   backward: dx[c][b * HW + p] = keep ? g[p][b][c] * scale : 0             (the table takes no gradient)
+// (alphatriangle/nn/model.py:268-283 permutes, adds the table and applies nn.Dropout as three ops.)  One workgroup moves a
+// 32 x 32 tile through LDS, so both sides are read and written in whole 128-byte runs; the keep mask hashes the flat
+// token index, like the other dropout kernels here.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void tokens_pe_kernel(const T* __restrict__ x, const float* __restrict__ pe, const float* __restrict__ g,
+                                                        float* __restrict__ tokens, T* __restrict__ dx, const long long* __restrict__ seed,
+                                                        int D, int B, int HW, unsigned thresh, float scale) {
+  __shared__ float tile[32][33];
+  const int N = B * HW;
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tid = threadIdx.x;
+  const DropSeed s = thresh ? drop_seed(seed) : DropSeed{0u, 0u};
+  // token side: thread = (position nl, four channels c4 ..)
+  const int nl_t = tid >> 3, c4 = (tid & 7) * 4;
+  const int n_t = n0 + nl_t;
+  const int b_t = n_t / HW, p_t = n_t - b_t * HW;
+  const long long tok = ((long long)p_t * B + b_t) * D + c0 + c4;
+  // channel-major side: thread = (position nl, channels cr, cr + 8, ..)
+  const int nl_c = tid & 31, cr = tid >> 5;
+  if (!BWD) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = cr + 8 * i;
+      tile[c][nl_c] = n0 + nl_c < N ? load1<T>(x + (size_t)(c0 + c) * N + n0 + nl_c) : 0.f;
+    }
+    __syncthreads();
+    if (n_t < N) {
+      const float4 pv = *reinterpret_cast<const float4*>(pe + (size_t)p_t * D + c0 + c4);
+      float v[4] = {tile[c4][nl_t] + pv.x, tile[c4 + 1][nl_t] + pv.y, tile[c4 + 2][nl_t] + pv.z, tile[c4 + 3][nl_t] + pv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool keep = thresh == 0u || drop_hash32((unsigned)(tok + j), s.s0, s.s1) >= thresh;
+        v[j] = keep ? v[j] * scale : 0.f;
+      }
+      *reinterpret_cast<float4*>(tokens + tok) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  } else {
+    if (n_t < N) {
+      const float4 gv = *reinterpret_cast<const float4*>(g + tok);
+      const float v[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool keep = thresh == 0u || drop_hash32((unsigned)(tok + j), s.s0, s.s1) >= thresh;
+        tile[c4 + j][nl_t] = keep ? v[j] * scale : 0.f;
+      }
+    }
+    __syncthreads();
+    if (n0 + nl_c < N) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = cr + 8 * i;
+        const float v = tile[c][nl_c];
+        if constexpr (sizeof(T) == 2) dx[(size_t)(c0 + c) * N + n0 + nl_c] = float_to_bf16(v);
+        else dx[(size_t)(c0 + c) * N + n0 + nl_c] = v;
+      }
+    }
+  }
+}
+
 extern "C" {
 
 // out = a + dropout(b); a / out share a dtype, b may be bf16 next to fp32 a.  seed: one int64 on the device.
@@ -414,6 +476,27 @@ int atri_act_dropout(const void* h, const void* g, void* out, int is_bf16, const
     if (g) ATRI_ACT_DROPOUT(float, true); else ATRI_ACT_DROPOUT(float, false);
   }
 #undef ATRI_ACT_DROPOUT
+  return (int)hipGetLastError();
+}
+
+// Forward (g == nullptr): tokens [HW][B][D] (fp32) from x [D][B * HW] (fp32 or bf16) and the table pe [HW][D]; backward: dx from
+// the token gradient g.  D a multiple of 32; p_drop == 0: no dropout (seed may be null).
+int atri_tokens_pe(const void* x, int x_bf16, const float* pe, const float* g, float* tokens, void* dx, const long long* seed, int D,
+                   int B, int HW, float p_drop, hipStream_t s) {
+  if (D <= 0 || B <= 0 || HW <= 0) return 0;
+  if ((D & 31) || p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && seed == nullptr)) return (int)hipErrorInvalidValue;
+  if ((long long)B * HW * D >= (1LL << 32)) return (int)hipErrorInvalidValue;  // the mask hashes 32-bit token indices
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  const float scale = 1.0f / (1.0f - p_drop);
+  const dim3 grid((B * HW + 31) / 32, D / 32);
+#define ATRI_TOKENS(T, BWD) \
+  hipLaunchKernelGGL((tokens_pe_kernel<T, BWD>), grid, dim3(256), 0, s, (const T*)x, pe, g, tokens, (T*)dx, seed, D, B, HW, thresh, scale)
+  if (g == nullptr) {
+    if (x_bf16) ATRI_TOKENS(unsigned short, false); else ATRI_TOKENS(float, false);
+  } else {
+    if (x_bf16) ATRI_TOKENS(unsigned short, true); else ATRI_TOKENS(float, true);
+  }
+#undef ATRI_TOKENS
   return (int)hipGetLastError();
 }
 

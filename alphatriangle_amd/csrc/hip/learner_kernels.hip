@@ -476,7 +476,7 @@ template <typename T, typename TO, int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ g,
                                                      const float* __restrict__ b, TO* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows,
-                                                     float eps) {
+                                                     float eps, int perm_b) {
   constexpr int D = LPR * 8, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR;
@@ -505,7 +505,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   ln_load8<float>(b + sub * 8, bb);
 #pragma unroll
   for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * rstd * gg[j] + bb[j];
-  ln_store8<TO>(y + (size_t)row * D + sub * 8, f);
+  // perm_b > 0: input row p * perm_b + b (token-major [tokens][batch]) goes to output row b * (rows / perm_b) + p
+  // (batch-major), which is the flattening the layer after the encoder wants; statistics stay indexed by the input row
+  const int orow = perm_b > 0 ? (row % perm_b) * (rows / perm_b) + row / perm_b : row;
+  ln_store8<TO>(y + (size_t)orow * D + sub * 8, f);
   if (sub == 0) {
     mean_out[row] = mean;
     rstd_out[row] = rstd;
@@ -519,7 +522,7 @@ template <typename T, typename TG, int LPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const TG* __restrict__ dy,
                                                      const float* __restrict__ g, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, T* __restrict__ dx,
-                                                     float* __restrict__ partial, int rows, int rows_per_block) {
+                                                     float* __restrict__ partial, int rows, int rows_per_block, int perm_b) {
   constexpr int D = LPR * 8, RPW = 64 / LPR, RPB = 4 * RPW;  // rows per pass of the workgroup
   __shared__ float red[2][RPB][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -539,7 +542,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
     float mean = 0.f, rstd = 0.f;
     if (live) {
       ln_load8<T>(x + (size_t)row * D + sub * 8, xv);
-      ln_load8<TG>(dy + (size_t)row * D + sub * 8, dv);
+      const int grow = perm_b > 0 ? (row % perm_b) * (rows / perm_b) + row / perm_b : row;  // the forward's output row
+      ln_load8<TG>(dy + (size_t)grow * D + sub * 8, dv);
       mean = mean_in[row];
       rstd = rstd_in[row];
     }
@@ -584,16 +588,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
 namespace {
 template <typename T, typename TO, int LPR>
 void ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows, float eps,
-                   hipStream_t s) {
+                   int perm_b, hipStream_t s) {
   constexpr int RPB = 4 * (64 / LPR);
   hipLaunchKernelGGL((ln_fwd_kernel<T, TO, LPR>), dim3((rows + RPB - 1) / RPB), dim3(256), 0, s, (const T*)x, g, b, (TO*)y, mean,
-                     rstd, rows, eps);
+                     rstd, rows, eps, perm_b);
 }
 template <typename T, typename TG, int LPR>
 void ln_bwd_launch(const void* x, const void* dy, const float* g, const float* mean, const float* rstd, void* dx,
-                   float* partial, int rows, int rows_per_block, int blocks, hipStream_t s) {
+                   float* partial, int rows, int rows_per_block, int blocks, int perm_b, hipStream_t s) {
   hipLaunchKernelGGL((ln_bwd_kernel<T, TG, LPR>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const TG*)dy, g, mean, rstd, (T*)dx,
-                     partial, rows, rows_per_block);
+                     partial, rows, rows_per_block, perm_b);
 }
 }  // namespace
 
@@ -795,14 +799,17 @@ int atri_colsum(const void* g, int is_bf16, float* partial, float* out, int N, i
 
 // y = LayerNorm(x) over the last dimension D in {64, 128, 256, 512}; mean / rstd [rows] are saved for the backward pass.
 // is_bf16: dtype of x; out_bf16: dtype of y (fp32 rows may be written as bf16, not the other way round).
-int atri_ln_fwd(const void* x, int is_bf16, const float* g, const float* b, void* y, int out_bf16, float* mean, float* rstd,
-                int rows, int D, float eps, hipStream_t s) {
+// perm_b > 0 (rows a multiple of it): the rows are token-major [rows / perm_b tokens][perm_b samples] and y is written
+// batch-major [perm_b][rows / perm_b] - LayerNorm and the encoder's final flattening in one pass.
+int atri_ln_fwd_perm(const void* x, int is_bf16, const float* g, const float* b, void* y, int out_bf16, float* mean, float* rstd,
+                     int rows, int D, float eps, int perm_b, hipStream_t s) {
   if (rows <= 0) return 0;
   if (is_bf16 && !out_bf16) return (int)hipErrorInvalidValue;
-#define ATRI_LN_FWD(LPR)                                                                                     \
-  if (is_bf16) ln_fwd_launch<unsigned short, unsigned short, LPR>(x, g, b, y, mean, rstd, rows, eps, s);     \
-  else if (out_bf16) ln_fwd_launch<float, unsigned short, LPR>(x, g, b, y, mean, rstd, rows, eps, s);        \
-  else ln_fwd_launch<float, float, LPR>(x, g, b, y, mean, rstd, rows, eps, s)
+  if (perm_b < 0 || (perm_b > 0 && rows % perm_b != 0)) return (int)hipErrorInvalidValue;
+#define ATRI_LN_FWD(LPR)                                                                                             \
+  if (is_bf16) ln_fwd_launch<unsigned short, unsigned short, LPR>(x, g, b, y, mean, rstd, rows, eps, perm_b, s);     \
+  else if (out_bf16) ln_fwd_launch<float, unsigned short, LPR>(x, g, b, y, mean, rstd, rows, eps, perm_b, s);        \
+  else ln_fwd_launch<float, float, LPR>(x, g, b, y, mean, rstd, rows, eps, perm_b, s)
   switch (D) {
     case 64: ATRI_LN_FWD(8); break;
     case 128: ATRI_LN_FWD(16); break;
@@ -814,19 +821,26 @@ int atri_ln_fwd(const void* x, int is_bf16, const float* g, const float* b, void
   return (int)hipGetLastError();
 }
 
+int atri_ln_fwd(const void* x, int is_bf16, const float* g, const float* b, void* y, int out_bf16, float* mean, float* rstd,
+                int rows, int D, float eps, hipStream_t s) {
+  return atri_ln_fwd_perm(x, is_bf16, g, b, y, out_bf16, mean, rstd, rows, D, eps, 0, s);
+}
+
 // dx, dgamma, dbeta of LayerNorm.  partial holds blocks * 2 * D floats with blocks = ceil(rows / rows_per_block);
 // rows_per_block must be a multiple of 32.
 // is_bf16: dtype of x and dx; dy_bf16: dtype of dy (that of the forward's output).
-int atri_ln_bwd(const void* x, const void* dy, int is_bf16, int dy_bf16, const float* g, const float* mean, const float* rstd,
-                void* dx, float* partial, float* dgamma, float* dbeta, int rows, int D, int rows_per_block, hipStream_t s) {
+int atri_ln_bwd_perm(const void* x, const void* dy, int is_bf16, int dy_bf16, const float* g, const float* mean, const float* rstd,
+                     void* dx, float* partial, float* dgamma, float* dbeta, int rows, int D, int rows_per_block, int perm_b,
+                     hipStream_t s) {
   if (rows <= 0) return 0;
   if (rows_per_block <= 0 || (rows_per_block & 31)) return (int)hipErrorInvalidValue;
+  if (perm_b < 0 || (perm_b > 0 && rows % perm_b != 0)) return (int)hipErrorInvalidValue;
   if (is_bf16 && !dy_bf16) return (int)hipErrorInvalidValue;
   const int blocks = (rows + rows_per_block - 1) / rows_per_block;
 #define ATRI_LN_BWD(LPR)                                                                                                               \
-  if (is_bf16) ln_bwd_launch<unsigned short, unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, s); \
-  else if (dy_bf16) ln_bwd_launch<float, unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, s);     \
-  else ln_bwd_launch<float, float, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, s)
+  if (is_bf16) ln_bwd_launch<unsigned short, unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, perm_b, s); \
+  else if (dy_bf16) ln_bwd_launch<float, unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, perm_b, s);     \
+  else ln_bwd_launch<float, float, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, perm_b, s)
   switch (D) {
     case 64: ATRI_LN_BWD(8); break;
     case 128: ATRI_LN_BWD(16); break;
@@ -839,6 +853,11 @@ int atri_ln_bwd(const void* x, const void* dy, int is_bf16, int dy_bf16, const f
   launch_colsum_final(partial, dgamma, blocks, 2 * D, s);
   (void)dbeta;  // dgamma and dbeta are the two halves of one [2 * D] buffer
   return (int)hipGetLastError();
+}
+
+int atri_ln_bwd(const void* x, const void* dy, int is_bf16, int dy_bf16, const float* g, const float* mean, const float* rstd,
+                void* dx, float* partial, float* dgamma, float* dbeta, int rows, int D, int rows_per_block, hipStream_t s) {
+  return atri_ln_bwd_perm(x, dy, is_bf16, dy_bf16, g, mean, rstd, dx, partial, dgamma, dbeta, rows, D, rows_per_block, 0, s);
 }
 
 // cols [C*kh*kw, B*oh*ow] = patch matrix of x [C, B, H, W] (bf16 or f32, stride 1, zero padding ph / pw); 3x3 and 5x5 kernels.

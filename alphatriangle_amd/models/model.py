@@ -516,7 +516,9 @@ class _LayerNormFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:  # noqa: ANN001
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, batch_major_out: bool = False) -> torch.Tensor:  # noqa: ANN001
+        """``batch_major_out`` (``x`` is ``[tokens, batch, D]``): the result comes out as ``[batch, tokens * D]`` - the
+        permute + flatten in front of the shared layer done by the same pass (and undone by the backward kernel)."""
         from ..ops import hip_learner
 
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
@@ -524,32 +526,61 @@ class _LayerNormFn(torch.autograd.Function):
         out_dtype = x2.dtype
         if x2.dtype == torch.float32 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
             out_dtype = torch.bfloat16
-        y, mean, rstd = hip_learner.layer_norm_forward(x2, w32, b32, eps, out_dtype)
+        perm = int(x.shape[1]) if batch_major_out else 0
+        y, mean, rstd = hip_learner.layer_norm_forward(x2, w32, b32, eps, out_dtype, perm)
         ctx.save_for_backward(x2, w32, mean, rstd)
         ctx.shape = x.shape
-        return y.view(x.shape)
+        ctx.perm = perm
+        return y.view(x.shape[1], -1) if batch_major_out else y.view(x.shape)
 
     @staticmethod
     def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
         from ..ops import hip_learner
 
         x2, w32, mean, rstd = ctx.saved_tensors
-        dy2 = grad_out.reshape(x2.shape)
+        dy2 = grad_out.reshape(x2.shape)  # with ctx.perm: batch-major rows, which the kernel reads through the same permutation
         if dy2.dtype != torch.bfloat16 or x2.dtype != torch.float32:  # bf16 gradients of fp32 rows are read as they are
             dy2 = dy2.to(x2.dtype)
         dy2 = dy2.contiguous()
-        dx, dg, db = hip_learner.layer_norm_backward(x2, dy2, w32, mean, rstd)
-        return dx.view(ctx.shape), dg, db, None
+        dx, dg, db = hip_learner.layer_norm_backward(x2, dy2, w32, mean, rstd, ctx.perm)
+        return dx.view(ctx.shape), dg, db, None, None
+
+
+class _TokensPe(torch.autograd.Function):
+    """Channel-major body output ``[D, B, H, W]`` -> encoder tokens ``[H * W, B, D]`` with the positional table added and
+    its dropout applied, one launch each way (``ops.hip_learner.tokens_pe_*``) instead of a permuting copy, an add and
+    ``nn.Dropout`` (alphatriangle/nn/model.py:268-283).  The table is a buffer and takes no gradient."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, pe: torch.Tensor, p_drop: float) -> torch.Tensor:  # noqa: ANN001
+        from ..ops import hip_learner
+
+        tokens, seed = hip_learner.tokens_pe_forward(x, pe, p_drop)
+        ctx.save_for_backward(seed if seed is not None else tokens.new_empty(0))
+        ctx.p_drop, ctx.x_shape, ctx.x_dtype = p_drop, tuple(x.shape), x.dtype
+        return tokens
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        (seed,) = ctx.saved_tensors
+        return hip_learner.tokens_pe_backward(grad_out, seed if ctx.p_drop > 0 else None, ctx.p_drop, ctx.x_shape, ctx.x_dtype), None, None
 
 
 class FastLayerNorm(nn.LayerNorm):
     """``nn.LayerNorm`` (same parameters, same ``state_dict`` keys) whose GPU path is :class:`_LayerNormFn`."""
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if (
+    def fast_ok(self, x: torch.Tensor) -> bool:
+        """Whether the kernels take ``x`` (else the stock implementation does)."""
+        return bool(
             x.is_cuda and self.elementwise_affine and self.bias is not None and len(self.normalized_shape) == 1
             and self.normalized_shape[0] in (64, 128, 256, 512) and x.dtype in (torch.bfloat16, torch.float32)
-        ):
+            and x.shape[-1] == self.normalized_shape[0]
+        )
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.fast_ok(x):
             return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return super().forward(x)
 
@@ -928,10 +959,35 @@ class AlphaTriangleNet(nn.Module):
         x = self._cm_apply(self.res_body, self._cm_apply(self.conv_body, x))
         if self.uses_transformer and self.transformer_body is not None and self.pos_encoder is not None:
             x = self._cm_apply(self.input_proj, x)
-            tokens = x.flatten(2).permute(2, 1, 0).contiguous()  # [H*W, B, D]
-            tokens = self.transformer_body(self.pos_encoder(tokens))
-            return tokens.permute(1, 0, 2).flatten(1)
+            fused = self._encoder_io_fused(x)
+            if fused:
+                pe: torch.Tensor = self.pos_encoder.pe  # type: ignore[assignment]
+                p = float(self.pos_encoder.dropout.p) if self.training else 0.0
+                tokens = _TokensPe.apply(x.contiguous(), pe[: x.shape[2] * x.shape[3], 0, :], p)
+            else:
+                tokens = self.pos_encoder(x.flatten(2).permute(2, 1, 0).contiguous())  # [H*W, B, D]
+            body = self.transformer_body
+            norm = body.norm
+            if fused and isinstance(norm, FastLayerNorm) and norm.fast_ok(tokens):
+                for layer in body.layers:  # the stack written out, so that the final LayerNorm can write [B, H*W*D] itself
+                    tokens = layer(tokens)
+                return _LayerNormFn.apply(tokens, norm.weight, norm.bias, norm.eps, True)
+            return body(tokens).permute(1, 0, 2).flatten(1)
         return x.permute(1, 0, 2, 3).reshape(x.size(1), -1)
+
+    fused_encoder_io = True  # learner fast path: tokens + positional table + dropout in one launch, final LayerNorm writes the flattened rows
+
+    def _encoder_io_fused(self, x: torch.Tensor) -> bool:
+        from ..ops import hip_learner
+
+        if not (self.fused_encoder_io and self.pos_encoder is not None and x.is_cuda and torch.is_grad_enabled()):
+            return False
+        p = float(self.pos_encoder.dropout.p) if self.training else 0.0
+        pe: torch.Tensor = self.pos_encoder.pe  # type: ignore[assignment]
+        hw = int(x.shape[2] * x.shape[3])
+        if not (0.0 <= p < 1.0) or hw > pe.shape[0] or x.shape[0] != pe.shape[2]:
+            return False
+        return hip_learner.tokens_pe_supported(x.contiguous(), pe[:hw, 0, :])
 
     def body(self, grid_state: torch.Tensor) -> torch.Tensor:
         """Feature extractor up to (and excluding) the shared FC: returns ``[B, feat]``."""

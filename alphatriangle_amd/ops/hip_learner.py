@@ -116,11 +116,12 @@ LN_WIDTHS = (64, 128, 256, 512)
 
 
 def layer_norm_forward(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
-                       out_dtype: torch.dtype | None = None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                       out_dtype: torch.dtype | None = None, perm_batch: int = 0) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``y, mean, rstd`` of LayerNorm over the last dimension of a contiguous ``[rows, D]`` bf16 / fp32 matrix.
 
     ``out_dtype=torch.bfloat16`` with fp32 rows writes the normalised rows as bf16 (what an autocast GEMM would cast them
-    to anyway).
+    to anyway).  ``perm_batch = B > 0``: the rows are token-major ``[tokens][B]`` and ``y`` comes out batch-major
+    ``[B][tokens]`` (the flattening in front of the shared layer, done by the same pass).
     """
     rows, d = x2.shape
     out_dtype = x2.dtype if out_dtype is None else out_dtype
@@ -129,13 +130,14 @@ def layer_norm_forward(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tenso
     y = torch.empty(rows, d, dtype=out_dtype, device=x2.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
-    hb.call("atri_ln_fwd", hb.ptr(x2), hb.i32(1 if x2.dtype == torch.bfloat16 else 0), hb.ptr(weight), hb.ptr(bias), hb.ptr(y),
-            hb.i32(1 if out_dtype == torch.bfloat16 else 0), hb.ptr(mean), hb.ptr(rstd), hb.i32(rows), hb.i32(d), hb.f32(eps))
+    hb.call("atri_ln_fwd_perm", hb.ptr(x2), hb.i32(1 if x2.dtype == torch.bfloat16 else 0), hb.ptr(weight), hb.ptr(bias), hb.ptr(y),
+            hb.i32(1 if out_dtype == torch.bfloat16 else 0), hb.ptr(mean), hb.ptr(rstd), hb.i32(rows), hb.i32(d), hb.f32(eps),
+            hb.i32(perm_batch))
     return y, mean, rstd
 
 
 def layer_norm_backward(x2: torch.Tensor, dy2: torch.Tensor, weight: torch.Tensor, mean: torch.Tensor,
-                        rstd: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                        rstd: torch.Tensor, perm_batch: int = 0) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``dx [rows, D]`` (dtype of x), ``dgamma [D]``, ``dbeta [D]`` (fp32); ``dy2`` in the dtype of x or, for fp32 rows, bf16."""
     rows, d = x2.shape
     rows_per_block = max(32, (rows + 511) // 512 + 31 & ~31)  # about 500 workgroups, whole 32-row passes
@@ -143,9 +145,9 @@ def layer_norm_backward(x2: torch.Tensor, dy2: torch.Tensor, weight: torch.Tenso
     dx = torch.empty_like(x2)
     partial = torch.empty(blocks * 2 * d, dtype=torch.float32, device=x2.device)
     dgb = torch.empty(2 * d, dtype=torch.float32, device=x2.device)
-    hb.call("atri_ln_bwd", hb.ptr(x2), hb.ptr(dy2), hb.i32(1 if x2.dtype == torch.bfloat16 else 0),
+    hb.call("atri_ln_bwd_perm", hb.ptr(x2), hb.ptr(dy2), hb.i32(1 if x2.dtype == torch.bfloat16 else 0),
             hb.i32(1 if dy2.dtype == torch.bfloat16 else 0), hb.ptr(weight), hb.ptr(mean), hb.ptr(rstd), hb.ptr(dx), hb.ptr(partial),
-            hb.ptr(dgb), hb.ptr(dgb[d:]), hb.i32(rows), hb.i32(d), hb.i32(rows_per_block))
+            hb.ptr(dgb), hb.ptr(dgb[d:]), hb.i32(rows), hb.i32(d), hb.i32(rows_per_block), hb.i32(perm_batch))
     return dx, dgb[:d], dgb[d:]
 
 
@@ -465,6 +467,36 @@ def conv3_wgrad_cm(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
     hb.call("atri_conv3_wgrad", hb.ptr(g), hb.ptr(x), hb.ptr(part), hb.ptr(dw), hb.i32(cin), hb.i32(cout), hb.i32(nb), hb.i32(h), hb.i32(w))
     return dw
+
+
+def tokens_pe_supported(x: torch.Tensor, pe: torch.Tensor) -> bool:
+    """True when :func:`tokens_pe_forward` handles channel-major ``x [D, B, H, W]`` and the table ``pe [H * W, D]``."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and available()):
+        return False
+    d, b, h, w = (int(v) for v in x.shape)
+    return bool(d % 32 == 0 and pe.dtype == torch.float32 and pe.is_contiguous() and tuple(pe.shape) == (h * w, d) and pe.device == x.device
+                and b * h * w * d < 2**32 and pe.data_ptr() % 16 == 0)
+
+
+def tokens_pe_forward(x: torch.Tensor, pe: torch.Tensor, p_drop: float) -> tuple[torch.Tensor, torch.Tensor | None]:
+    """Encoder tokens ``[H * W, B, D]`` (fp32) = dropout(``x`` permuted + ``pe``) from the channel-major body output in one launch;
+    returns them with the seed of the keep mask (``None`` without dropout)."""
+    d, b, h, w = (int(v) for v in x.shape)
+    tokens = torch.empty(h * w, b, d, dtype=torch.float32, device=x.device)
+    seed = _drop_seed(x.device) if p_drop > 0 else None
+    hb.call("atri_tokens_pe", hb.ptr(x), hb.i32(1 if x.dtype == torch.bfloat16 else 0), hb.ptr(pe), hb.ptr(None), hb.ptr(tokens), hb.ptr(None),
+            hb.ptr(seed), hb.i32(d), hb.i32(b), hb.i32(h * w), hb.f32(p_drop))
+    return tokens, seed
+
+
+def tokens_pe_backward(g: torch.Tensor, seed: torch.Tensor | None, p_drop: float, shape: tuple[int, ...], dtype: torch.dtype) -> torch.Tensor:
+    """Gradient of the channel-major input ``[D, B, H, W]`` (in ``dtype``) from the token gradient ``g [H * W, B, D]`` (fp32)."""
+    d, b, h, w = (int(v) for v in shape)
+    g = g.float().contiguous()
+    dx = torch.empty(d, b, h, w, dtype=dtype, device=g.device)
+    hb.call("atri_tokens_pe", hb.ptr(None), hb.i32(1 if dtype == torch.bfloat16 else 0), hb.ptr(None), hb.ptr(g), hb.ptr(None), hb.ptr(dx),
+            hb.ptr(seed), hb.i32(d), hb.i32(b), hb.i32(h * w), hb.f32(p_drop))
+    return dx
 
 
 def conv_wt(weight: torch.Tensor) -> torch.Tensor:

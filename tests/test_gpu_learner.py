@@ -1020,6 +1020,63 @@ def test_fused_activation_dropout_matches_its_definition(dtype, act_id, p):
     assert (dh.double() - hd.grad).abs().max().item() < tol * max(1.0, hd.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d,b,h,w,p", [(128, 256, 8, 15, 0.1), (128, 3, 8, 15, 0.0), (64, 5, 5, 6, 0.3), (128, 2, 12, 21, 0.1)])
+def test_tokens_kernel_matches_permute_add_dropout(dtype, d, b, h, w, p):
+    """Channel-major body output -> tokens + positional table + dropout in one launch (and its backward) against the three ops
+    it replaces, with the keep mask re-stated on the host."""
+    from alphatriangle_amd.models.model import _TokensPe, sinusoid_table
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(91)
+    dev = torch.device("cuda")
+    x = torch.randn(d, b, h, w, device=dev).to(dtype).requires_grad_(True)
+    pe = sinusoid_table(h * w, d).to(dev)
+    assert hip_learner.tokens_pe_supported(x, pe)
+    hip_learner.begin_step_seeds(dev)
+    try:
+        tokens = _TokensPe.apply(x, pe, p)
+        seed = int(hip_learner._seed_pool[hip_learner._dev_index(dev)][0][0]) if p > 0 else 0
+    finally:
+        hip_learner.end_step_seeds(dev)
+    plain = x.detach().float().flatten(2).permute(2, 1, 0) + pe.unsqueeze(1)  # [HW, B, D]
+    keep = _flat_keep_mask(seed, plain.numel(), p, dev).view(plain.shape) if p > 0 else torch.ones_like(plain, dtype=torch.bool)
+    ref = torch.where(keep, plain / (1.0 - p), torch.zeros_like(plain))
+    assert tokens.dtype == torch.float32 and tokens.shape == ref.shape
+    assert torch.allclose(tokens, ref, rtol=1e-6, atol=1e-6)
+    if p > 0:
+        share = 1.0 - keep.float().mean().item()
+        assert abs(share - p) < 0.02, share
+    g = torch.randn_like(tokens)
+    tokens.backward(g)
+    dref = torch.where(keep, g / (1.0 - p), torch.zeros_like(g)).permute(2, 1, 0).reshape(d, b, h, w)
+    assert x.grad.dtype == dtype
+    assert torch.allclose(x.grad.float(), dref.to(dtype).float(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layer_norm_writing_batch_major_rows_matches_norm_then_permute(dtype):
+    from alphatriangle_amd.models.model import _LayerNormFn
+
+    torch.manual_seed(93)
+    dev = torch.device("cuda")
+    L, B, D = 120, 37, 128
+    x = torch.randn(L, B, D, device=dev).to(dtype).requires_grad_(True)
+    w = torch.rand(D, device=dev, requires_grad=True)
+    bias = torch.randn(D, device=dev, requires_grad=True)
+    y = _LayerNormFn.apply(x, w, bias, 1e-5, True)
+    xr, wr, br = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True), bias.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-5).permute(1, 0, 2).flatten(1)
+    assert y.shape == (B, L * D)
+    tol = 3e-2 if dtype == torch.bfloat16 else 2e-5
+    assert (y.double() - yr).abs().max().item() < tol
+    g = torch.randn(B, L * D, device=dev)
+    y.backward(g.to(y.dtype))
+    yr.backward(g.to(y.dtype).double())
+    assert (x.grad.double() - xr.grad).abs().max().item() < tol * 3
+    assert (w.grad.double() - wr.grad).abs().max().item() < tol * 30 and (bias.grad.double() - br.grad).abs().max().item() < tol * 30
+
+
 def test_encoder_layer_with_fused_dropout_trains_like_the_stock_modules_in_eval_and_differs_only_by_its_masks():
     """Evaluation mode: identical outputs with and without the fused dropout ops.  Training mode: the layer runs, the
     fused path really drops (outputs differ between two calls) and gradients reach every parameter."""
