@@ -522,7 +522,8 @@ template <typename T, typename TG, int LPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const TG* __restrict__ dy,
                                                      const float* __restrict__ g, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, T* __restrict__ dx,
-                                                     float* __restrict__ partial, int rows, int rows_per_block, int perm_b) {
+                                                     float* __restrict__ partial, int rows, int rows_per_block, int perm_b,
+                                                     const T* __restrict__ skip) {
   constexpr int D = LPR * 8, RPW = 64 / LPR, RPB = 4 * RPW;  // rows per pass of the workgroup
   __shared__ float red[2][RPB][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -567,6 +568,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
     if (live) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) dv[j] = rstd * (dv[j] - c1 - xv[j] * c2);
+      if (skip != nullptr) {  // gradient that reaches x past the normalisation (the residual connection): added here
+        float sk[8];
+        ln_load8<T>(skip + (size_t)row * D + sub * 8, sk);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[j] += sk[j];
+      }
       ln_store8<T>(dx + (size_t)row * D + sub * 8, dv);
     }
   }
@@ -595,9 +602,9 @@ void ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float
 }
 template <typename T, typename TG, int LPR>
 void ln_bwd_launch(const void* x, const void* dy, const float* g, const float* mean, const float* rstd, void* dx,
-                   float* partial, int rows, int rows_per_block, int blocks, int perm_b, hipStream_t s) {
+                   float* partial, int rows, int rows_per_block, int blocks, int perm_b, const void* skip, hipStream_t s) {
   hipLaunchKernelGGL((ln_bwd_kernel<T, TG, LPR>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const TG*)dy, g, mean, rstd, (T*)dx,
-                     partial, rows, rows_per_block, perm_b);
+                     partial, rows, rows_per_block, perm_b, (const T*)skip);
 }
 }  // namespace
 
@@ -829,18 +836,19 @@ int atri_ln_fwd(const void* x, int is_bf16, const float* g, const float* b, void
 // dx, dgamma, dbeta of LayerNorm.  partial holds blocks * 2 * D floats with blocks = ceil(rows / rows_per_block);
 // rows_per_block must be a multiple of 32.
 // is_bf16: dtype of x and dx; dy_bf16: dtype of dy (that of the forward's output).
+// skip (optional, dtype of x): a gradient that reaches x around the normalisation; dx = skip + LayerNorm'(dy).
 int atri_ln_bwd_perm(const void* x, const void* dy, int is_bf16, int dy_bf16, const float* g, const float* mean, const float* rstd,
                      void* dx, float* partial, float* dgamma, float* dbeta, int rows, int D, int rows_per_block, int perm_b,
-                     hipStream_t s) {
+                     const void* skip, hipStream_t s) {
   if (rows <= 0) return 0;
   if (rows_per_block <= 0 || (rows_per_block & 31)) return (int)hipErrorInvalidValue;
   if (perm_b < 0 || (perm_b > 0 && rows % perm_b != 0)) return (int)hipErrorInvalidValue;
   if (is_bf16 && !dy_bf16) return (int)hipErrorInvalidValue;
   const int blocks = (rows + rows_per_block - 1) / rows_per_block;
 #define ATRI_LN_BWD(LPR)                                                                                                               \
-  if (is_bf16) ln_bwd_launch<unsigned short, unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, perm_b, s); \
-  else if (dy_bf16) ln_bwd_launch<float, unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, perm_b, s);     \
-  else ln_bwd_launch<float, float, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, perm_b, s)
+  if (is_bf16) ln_bwd_launch<unsigned short, unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, perm_b, skip, s); \
+  else if (dy_bf16) ln_bwd_launch<float, unsigned short, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, perm_b, skip, s);     \
+  else ln_bwd_launch<float, float, LPR>(x, dy, g, mean, rstd, dx, partial, rows, rows_per_block, blocks, perm_b, skip, s)
   switch (D) {
     case 64: ATRI_LN_BWD(8); break;
     case 128: ATRI_LN_BWD(16); break;
@@ -857,7 +865,7 @@ int atri_ln_bwd_perm(const void* x, const void* dy, int is_bf16, int dy_bf16, co
 
 int atri_ln_bwd(const void* x, const void* dy, int is_bf16, int dy_bf16, const float* g, const float* mean, const float* rstd,
                 void* dx, float* partial, float* dgamma, float* dbeta, int rows, int D, int rows_per_block, hipStream_t s) {
-  return atri_ln_bwd_perm(x, dy, is_bf16, dy_bf16, g, mean, rstd, dx, partial, dgamma, dbeta, rows, D, rows_per_block, 0, s);
+  return atri_ln_bwd_perm(x, dy, is_bf16, dy_bf16, g, mean, rstd, dx, partial, dgamma, dbeta, rows, D, rows_per_block, 0, nullptr, s);
 }
 
 // cols [C*kh*kw, B*oh*ow] = patch matrix of x [C, B, H, W] (bf16 or f32, stride 1, zero padding ph / pw); 3x3 and 5x5 kernels.

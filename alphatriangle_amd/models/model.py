@@ -546,6 +546,43 @@ class _LayerNormFn(torch.autograd.Function):
         return dx.view(ctx.shape), dg, db, None, None
 
 
+class _NormFork(torch.autograd.Function):
+    """``(x, LayerNorm(x))``: the fork of a pre-norm residual branch as ONE autograd node.
+
+    The residual connection and the normalised branch both start at ``x``; as two consumers of one tensor their
+    gradients would be added by a kernel of autograd's own (four per step for two encoder layers).  Here the first output
+    aliases ``x``, so ``x`` has a single consumer, and the backward kernel adds the gradient that arrives through the
+    alias to the LayerNorm gradient while it writes it (``ln_bwd_kernel``'s ``skip`` operand)."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float):  # noqa: ANN001, ANN205
+        from ..ops import hip_learner
+
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        w32, b32 = weight.float().contiguous(), bias.float().contiguous()
+        out_dtype = x2.dtype
+        if x2.dtype == torch.float32 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            out_dtype = torch.bfloat16
+        y, mean, rstd = hip_learner.layer_norm_forward(x2, w32, b32, eps, out_dtype)
+        ctx.save_for_backward(x2, w32, mean, rstd)
+        ctx.shape = x.shape
+        return x.view_as(x), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g_skip, g_y):  # noqa: ANN001
+        from ..ops import hip_learner
+
+        x2, w32, mean, rstd = ctx.saved_tensors
+        if g_y is None:
+            return g_skip, None, None, None
+        dy2 = g_y.reshape(x2.shape)
+        if dy2.dtype != torch.bfloat16 or x2.dtype != torch.float32:
+            dy2 = dy2.to(x2.dtype)
+        skip = g_skip.reshape(x2.shape).to(x2.dtype).contiguous() if g_skip is not None else None
+        dx, dg, db = hip_learner.layer_norm_backward(x2, dy2.contiguous(), w32, mean, rstd, 0, skip)
+        return dx.view(ctx.shape), dg, db, None
+
+
 class _TokensPe(torch.autograd.Function):
     """Channel-major body output ``[D, B, H, W]`` -> encoder tokens ``[H * W, B, D]`` with the positional table added and
     its dropout applied, one launch each way (``ops.hip_learner.tokens_pe_*``) instead of a permuting copy, an add and
@@ -692,12 +729,21 @@ class EncoderLayer(nn.TransformerEncoderLayer):
         attn = self.self_attn
         seq, batch, dim = src.shape
         heads = attn.num_heads
-        y = self.norm1(src)
+        src, y = self._norm_fork(self.norm1, src)
         qkv = _linear_rows(y, attn.in_proj_weight, attn.in_proj_bias)  # [L, B, 3D]
         ctx = self._attention(qkv, seq, batch, dim, heads)
         x = self._add_dropout(src, _linear_rows(ctx, attn.out_proj.weight, attn.out_proj.bias), self.dropout1)
-        hidden = self._act_dropout(_linear_rows(self.norm2(x), self.linear1.weight, self.linear1.bias))
+        x, y2 = self._norm_fork(self.norm2, x)
+        hidden = self._act_dropout(_linear_rows(y2, self.linear1.weight, self.linear1.bias))
         return self._add_dropout(x, _linear_rows(hidden, self.linear2.weight, self.linear2.bias), self.dropout2)
+
+    fused_norm_fork = True  # residual fork + LayerNorm as one autograd node (tests flip this)
+
+    def _norm_fork(self, norm: nn.Module, t: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """``(t, norm(t))`` - as one node whose backward kernel adds the two gradients of ``t`` when the kernels take it."""
+        if self.fused_norm_fork and isinstance(norm, FastLayerNorm) and norm.fast_ok(t) and torch.is_grad_enabled() and t.requires_grad:
+            return _NormFork.apply(t, norm.weight, norm.bias, norm.eps)
+        return t, norm(t)
 
     fused_dropout = True  # dropout fused with the residual adds / the FFN activation on the GPU (False: stock modules)
 

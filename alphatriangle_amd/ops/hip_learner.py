@@ -137,7 +137,7 @@ def layer_norm_forward(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tenso
 
 
 def layer_norm_backward(x2: torch.Tensor, dy2: torch.Tensor, weight: torch.Tensor, mean: torch.Tensor,
-                        rstd: torch.Tensor, perm_batch: int = 0) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                        rstd: torch.Tensor, perm_batch: int = 0, skip: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``dx [rows, D]`` (dtype of x), ``dgamma [D]``, ``dbeta [D]`` (fp32); ``dy2`` in the dtype of x or, for fp32 rows, bf16."""
     rows, d = x2.shape
     rows_per_block = max(32, (rows + 511) // 512 + 31 & ~31)  # about 500 workgroups, whole 32-row passes
@@ -147,7 +147,7 @@ def layer_norm_backward(x2: torch.Tensor, dy2: torch.Tensor, weight: torch.Tenso
     dgb = torch.empty(2 * d, dtype=torch.float32, device=x2.device)
     hb.call("atri_ln_bwd_perm", hb.ptr(x2), hb.ptr(dy2), hb.i32(1 if x2.dtype == torch.bfloat16 else 0),
             hb.i32(1 if dy2.dtype == torch.bfloat16 else 0), hb.ptr(weight), hb.ptr(mean), hb.ptr(rstd), hb.ptr(dx), hb.ptr(partial),
-            hb.ptr(dgb), hb.ptr(dgb[d:]), hb.i32(rows), hb.i32(d), hb.i32(rows_per_block), hb.i32(perm_batch))
+            hb.ptr(dgb), hb.ptr(dgb[d:]), hb.i32(rows), hb.i32(d), hb.i32(rows_per_block), hb.i32(perm_batch), hb.ptr(skip))
     return dx, dgb[:d], dgb[d:]
 
 

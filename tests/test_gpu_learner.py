@@ -1077,6 +1077,40 @@ def test_layer_norm_writing_batch_major_rows_matches_norm_then_permute(dtype):
     assert (w.grad.double() - wr.grad).abs().max().item() < tol * 30 and (bias.grad.double() - br.grad).abs().max().item() < tol * 30
 
 
+@pytest.mark.parametrize("low", [False, True])
+def test_residual_fork_node_gives_the_gradients_of_separate_norm_and_skip(low):
+    """EncoderLayer with the (x, LayerNorm(x)) fork as one autograd node (the skip gradient added inside the LayerNorm backward
+    kernel) against the same layer with the two consumers of x left to autograd: same output, same gradients."""
+    import copy
+
+    from alphatriangle_amd.models.model import EncoderLayer
+
+    torch.manual_seed(97)
+    dev = torch.device("cuda")
+    layer_a = EncoderLayer(d_model=128, nhead=4, dim_feedforward=256, activation="relu", batch_first=False, norm_first=True).to(dev).train()
+    for m in layer_a.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    layer_a.self_attn.dropout = 0.0
+    layer_b = copy.deepcopy(layer_a)
+    layer_b.fused_norm_fork = False
+    x0 = torch.randn(120, 16, 128, device=dev)
+    g = torch.randn(120, 16, 128, device=dev)
+    res = []
+    for layer in (layer_a, layer_b):
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=low):
+            y = layer(x)
+        y.backward(g.to(y.dtype))
+        res.append((y.detach().float(), x.grad.float(), {n: p.grad.float() for n, p in layer.named_parameters()}))
+    tol = 2e-2 if low else 1e-5
+    assert torch.allclose(res[0][0], res[1][0], rtol=tol, atol=tol)
+    assert torch.allclose(res[0][1], res[1][1], rtol=tol, atol=tol * max(1.0, res[1][1].abs().max().item()))
+    for name, ga in res[0][2].items():
+        gb = res[1][2][name]
+        assert (ga - gb).abs().max().item() <= tol * max(1.0, gb.abs().max().item()), name
+
+
 def test_encoder_layer_with_fused_dropout_trains_like_the_stock_modules_in_eval_and_differs_only_by_its_masks():
     """Evaluation mode: identical outputs with and without the fused dropout ops.  Training mode: the layer runs, the
     fused path really drops (outputs differ between two calls) and gradients reach every parameter."""
