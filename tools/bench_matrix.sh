@@ -8,7 +8,7 @@ out="$root/gpurun_out/$name"
 mkdir -p "$out"
 cd "$root"
 for args in "$@"; do
-  timeout -k 10 500 python3 -u bench.py $args 2> "$out/last.err" | python3 -c "
+  timeout -k 10 500 python3 -u bench.py --no-all-configs $args 2> "$out/last.err" | python3 -c "
 import json, sys
 d = json.loads(sys.stdin.read())
 print('$args |', d['value'], 'moves/s |', d['ms_per_step'], 'ms |', d.get('leaf_slots_needing_evaluation'), '|', d.get('trainer_samples_per_sec_unthrottled'))" | tee -a "$out/matrix.txt"

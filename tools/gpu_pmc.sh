@@ -7,7 +7,7 @@ root="$(cd "$(dirname "$0")/.." && pwd)"
 out="$root/gpurun_out/$name"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --pmc $counters --output-format csv -d "$out" -o p -- python3 "$root/bench.py" "$@" > "$out/bench.log" 2>&1
+timeout -s KILL 240 rocprofv3 --pmc $counters --output-format csv -d "$out" -o p -- python3 "$root/bench.py" --no-all-configs "$@" > "$out/bench.log" 2>&1
 cd "$root"
 python3 tools/pmc_summary.py "$out/p_counter_collection.csv" > "$out/pmc.txt"
 head -8 "$out/pmc.txt" | cut -c1-220

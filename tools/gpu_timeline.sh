@@ -7,7 +7,7 @@ root="$(cd "$(dirname "$0")/.." && pwd)"
 out="$root/gpurun_out/$name"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$out" -o run -- python3 "$root/bench.py" "$@" > "$out/bench.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$out" -o run -- python3 "$root/bench.py" --no-all-configs "$@" > "$out/bench.log" 2>&1
 cd "$root"
 for p in $positions; do
   echo "--- wave at $p of the trace" >> "$out/timeline.txt"
