@@ -447,6 +447,31 @@ __global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(const float* __
   }
 }
 
+// Every filter of a step in one launch: entry e = blockIdx.y (a filter and a direction), blockIdx.x walks its elements.
+constexpr int kPackMany = 24;
+struct Conv3PackMany {
+  const float* w[kPackMany];
+  unsigned short* hi[kPackMany];
+  unsigned short* lo[kPackMany];
+  int cout[kPackMany], cin[kPackMany], dgrad[kPackMany];
+};
+__global__ __launch_bounds__(256) void conv3_pack_many_kernel(Conv3PackMany a) {
+  const int e = blockIdx.y;
+  const int cout = a.cout[e], cin = a.cin[e];
+  const bool dg = a.dgrad[e] != 0;
+  const int M = dg ? cin : cout, K = dg ? cout : cin;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 9 * K * M) return;
+  const int kk = i & 31, m = (i >> 5) % M, rest = (i >> 5) / M;
+  const int kc = rest % (K / 32), tap = rest / (K / 32);
+  const int k = kc * 32 + kk;
+  const float* w = a.w[e];
+  const float v = dg ? w[((size_t)k * cin + m) * 9 + (8 - tap)] : w[((size_t)m * cin + k) * 9 + tap];
+  const unsigned short h = float_to_bf16(v);
+  a.hi[e][i] = h;
+  a.lo[e][i] = float_to_bf16(v - bf16_to_float(h));
+}
+
 namespace {
 template <int CIN, int COT, int NT>
 int launch_conv3(const Conv3CmArgs& a, int boards, hipStream_t s) {
@@ -481,6 +506,24 @@ int atri_conv3_pack(const float* w, unsigned short* hi, unsigned short* lo, int 
     hipLaunchKernelGGL(conv3_pack_kernel<true>, grid, dim3(256), 0, s, w, hi, lo, cout, cin);
   else
     hipLaunchKernelGGL(conv3_pack_kernel<false>, grid, dim3(256), 0, s, w, hi, lo, cout, cin);
+  return hip_err(hipGetLastError());
+}
+
+// n <= 24 filters (each fp32 [cout][cin][3][3]) packed in one launch; entry e is packed for the data gradient when dgrad[e] != 0.
+int atri_conv3_pack_many(int n, const float* const* w, unsigned short* const* hi, unsigned short* const* lo, const int* cout,
+                         const int* cin, const int* dgrad, hipStream_t s) {
+  if (n <= 0) return 0;
+  if (n > kPackMany) return (int)hipErrorInvalidValue;
+  Conv3PackMany a{};
+  int most = 0;
+  for (int e = 0; e < n; ++e) {
+    const int K = dgrad[e] ? cout[e] : cin[e];
+    if (cout[e] <= 0 || cin[e] <= 0 || (K & 31)) return (int)hipErrorInvalidValue;
+    a.w[e] = w[e]; a.hi[e] = hi[e]; a.lo[e] = lo[e];
+    a.cout[e] = cout[e]; a.cin[e] = cin[e]; a.dgrad[e] = dgrad[e];
+    most = most > 9 * cout[e] * cin[e] ? most : 9 * cout[e] * cin[e];
+  }
+  hipLaunchKernelGGL(conv3_pack_many_kernel, dim3((most + 255) / 256, n), dim3(256), 0, s, a);
   return hip_err(hipGetLastError());
 }
 

@@ -213,7 +213,10 @@ class _ConvGemmCM(torch.autograd.Function):
                               and hip_learner.conv3_cm_supported(x, cout))
             if ctx.direct:
                 ctx.save_for_backward(x, weight)
-                return hip_learner.conv3_cm(x, hip_learner.conv3_pack(weight, False), cout)
+                packed = getattr(weight, "_atri_packed", None)  # AlphaTriangleNet.prepack_filters: all layers in one launch
+                ctx.packed_dgrad = packed.get(True) if packed else None
+                planes = packed.get(False) if packed else None
+                return hip_learner.conv3_cm(x, planes if planes is not None else hip_learner.conv3_pack(weight, False), cout)
             if kh == 1 and kw == 1:
                 cols = x.reshape(cin, b * h * w)
             elif x.is_cuda:
@@ -255,7 +258,8 @@ class _ConvGemmCM(torch.autograd.Function):
             if kh == 1 and kw == 1:
                 d_x = _mm(weight.reshape(cout, cin).t(), g.view(cout, -1)).view(cin, b, h, w)
             elif direct and hip_learner.conv3_cm_supported(g, cin):
-                d_x = hip_learner.conv3_cm(g, hip_learner.conv3_pack(weight, True), cin)
+                planes = getattr(ctx, "packed_dgrad", None)
+                d_x = hip_learner.conv3_cm(g, planes if planes is not None else hip_learner.conv3_pack(weight, True), cin)
             else:
                 w_t = _flipped_filter(weight)
                 if ctx.implicit and hip_learner.conv3_supported(g, w_t):
@@ -1046,6 +1050,44 @@ class AlphaTriangleNet(nn.Module):
             tokens = self.transformer_body(self.pos_encoder(tokens))
             return tokens.permute(1, 0, 2).flatten(1)
         return x.reshape(x.size(0), -1)
+
+    def prepack_filters(self) -> None:
+        """Pack the filters of every 3x3 convolution the board-per-workgroup kernel serves (forward form, and the flipped
+        form where the data gradient runs on it too) in ONE launch and attach them to their weights; :class:`_ConvGemmCM`
+        picks them up instead of packing layer by layer (eleven launches per step for the default network).  The packed
+        copies are only valid until the weights change: the caller releases them (:meth:`release_packed_filters`) before
+        the optimizer step."""
+        from ..ops import hip_learner
+
+        if not (FP32_GEMM_ON_BF16_CORES and DIRECT_CONV and hip_learner.available()):
+            return
+        h, w = int(self.env_config.ROWS), int(self.env_config.COLS)
+        jobs: list[tuple[torch.Tensor, bool]] = []
+        slots: list[tuple[torch.Tensor, bool]] = []
+        for m in self.modules():
+            if not (isinstance(m, GemmConv2d) and m.kernel_size == (3, 3) and m.padding == (1, 1) and m.stride == (1, 1) and m.groups == 1
+                    and m.weight.is_cuda and m.weight.dtype == torch.float32):
+                continue
+            cout, cin = int(m.out_channels), int(m.in_channels)
+            if not hip_learner.conv3_cm_sizes_ok(cin, cout, h, w):
+                continue
+            jobs.append((m.weight, False))
+            slots.append((m.weight, False))
+            if hip_learner.conv3_cm_sizes_ok(cout, cin, h, w):  # the data gradient is a cout -> cin convolution
+                jobs.append((m.weight, True))
+                slots.append((m.weight, True))
+        if not jobs:
+            return
+        for (weight, dgrad), planes in zip(slots, hip_learner.conv3_pack_many(jobs), strict=True):
+            packed = getattr(weight, "_atri_packed", None)
+            if packed is None:
+                packed = weight._atri_packed = {}
+            packed[dgrad] = planes
+
+    def release_packed_filters(self) -> None:
+        for p in self.parameters():
+            if hasattr(p, "_atri_packed"):
+                del p._atri_packed
 
     fused_tail = True  # learner fast path: shared layer and heads on the in-tree GEMM / BatchNorm1d kernels (tests flip this)
 

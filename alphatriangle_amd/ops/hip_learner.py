@@ -417,6 +417,15 @@ def conv3_cm_supported(x: torch.Tensor, cout: int) -> bool:
     return bool(nb >= 1 and cin * nb * h * w < 2**31 and fn(C.c_int(cin), C.c_int(int(cout)), C.c_int(h), C.c_int(w)))
 
 
+def conv3_cm_sizes_ok(cin: int, cout: int, h: int, w: int) -> bool:
+    """Whether :func:`conv3_cm` serves a ``cin -> cout`` convolution on ``h x w`` boards."""
+    if not available():
+        return False
+    fn = getattr(hb.lib(), "atri_conv3_cm_supported")
+    fn.restype = C.c_int
+    return bool(fn(C.c_int(int(cin)), C.c_int(int(cout)), C.c_int(int(h)), C.c_int(int(w))))
+
+
 def conv3_pack(weight: torch.Tensor, dgrad: bool) -> torch.Tensor:
     """The filter ``[Cout, Cin, 3, 3]`` (fp32) as the (hi, lo) bf16 planes :func:`conv3_cm` reads, ``[2, 9 * Cin * Cout]``:
     as it is for the forward product, flipped with the channels swapped for the data gradient.  One launch."""
@@ -427,6 +436,37 @@ def conv3_pack(weight: torch.Tensor, dgrad: bool) -> torch.Tensor:
     planes = torch.empty(2, 9 * cin * cout, dtype=torch.bfloat16, device=w.device)
     hb.call("atri_conv3_pack", hb.ptr(w), hb.ptr(planes[0]), hb.ptr(planes[1]), hb.i32(cout), hb.i32(cin), hb.i32(1 if dgrad else 0))
     return planes
+
+
+def conv3_pack_many(jobs: list[tuple[torch.Tensor, bool]]) -> list[torch.Tensor]:
+    """:func:`conv3_pack` for several ``(filter, dgrad)`` jobs in ONE launch (a learner step packs eleven: every direct
+    convolution's forward form and, where the data gradient runs on the kernel too, its flipped form)."""
+    if not jobs:
+        return []
+    if len(jobs) > 24:
+        return conv3_pack_many(jobs[:24]) + conv3_pack_many(jobs[24:])
+    dev = jobs[0][0].device
+    total = sum(2 * 9 * int(w.shape[0]) * int(w.shape[1]) for w, _ in jobs)
+    pool = torch.empty(total, dtype=torch.bfloat16, device=dev)
+    outs, off = [], 0
+    n = len(jobs)
+    wp, hp, lp = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    co, ci, dg = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+    keep = []
+    for e, (w, dgrad) in enumerate(jobs):
+        cout, cin, kh, kw = (int(v) for v in w.shape)
+        if (kh, kw) != (3, 3) or w.dtype != torch.float32 or w.device != dev:
+            raise ValueError("conv3_pack_many: needs fp32 [Cout, Cin, 3, 3] filters on one device")
+        wc = w.contiguous()
+        keep.append(wc)
+        cnt = 9 * cin * cout
+        planes = pool[off : off + 2 * cnt].view(2, cnt)
+        off += 2 * cnt
+        outs.append(planes)
+        wp[e], hp[e], lp[e] = wc.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr()
+        co[e], ci[e], dg[e] = cout, cin, 1 if dgrad else 0
+    hb.call("atri_conv3_pack_many", hb.i32(n), wp, hp, lp, co, ci, dg)
+    return outs
 
 
 def conv3_cm(x: torch.Tensor, planes: torch.Tensor, cout: int) -> torch.Tensor:

@@ -267,35 +267,43 @@ class Trainer:
         pooled_seeds = self.device.type == "cuda" and hip_learner.available()
         if pooled_seeds:
             hip_learner.begin_step_seeds(self.device)  # one generator launch for all dropout sites of this pass
+        core = getattr(self.nn, "_orig_model", self.model)
+        prepacked = pooled_seeds and not self.autocast_bf16 and hasattr(core, "prepack_filters")
+        if prepacked:
+            core.prepack_filters()  # one launch for the filters of every direct convolution; valid until the weights change
         try:
-            if self.autocast_bf16:
-                if self.flat is not None:
-                    self.flat.refresh_shadow(torch.bfloat16)  # one cast of the flat buffer instead of one per weight
-                with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            try:
+                if self.autocast_bf16:
+                    if self.flat is not None:
+                        self.flat.refresh_shadow(torch.bfloat16)  # one cast of the flat buffer instead of one per weight
+                    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                        policy_logits, value_logits = self.model(tb.grid, tb.other)
+                else:
                     policy_logits, value_logits = self.model(tb.grid, tb.other)
+            finally:
+                if pooled_seeds:
+                    hip_learner.end_step_seeds(self.device)
+            out = alphazero_loss(
+                policy_logits,
+                value_logits,
+                tb.policy_target,
+                tb.returns,
+                tb.weights,
+                v_min=self.v_min,
+                v_max=self.v_max,
+                policy_weight=self.train_config.POLICY_LOSS_WEIGHT,
+                value_weight=self.train_config.VALUE_LOSS_WEIGHT,
+                entropy_weight=self.train_config.ENTROPY_BONUS_WEIGHT,
+            )
+            if self.device.type == "cuda":
+                if self._grad_seed is None:
+                    self._grad_seed = torch.ones((), dtype=torch.float32, device=self.device)
+                out.total.backward(self._grad_seed.to(out.total.dtype))  # a kept 1.0 instead of a fill launch per step
             else:
-                policy_logits, value_logits = self.model(tb.grid, tb.other)
+                out.total.backward()
         finally:
-            if pooled_seeds:
-                hip_learner.end_step_seeds(self.device)
-        out = alphazero_loss(
-            policy_logits,
-            value_logits,
-            tb.policy_target,
-            tb.returns,
-            tb.weights,
-            v_min=self.v_min,
-            v_max=self.v_max,
-            policy_weight=self.train_config.POLICY_LOSS_WEIGHT,
-            value_weight=self.train_config.VALUE_LOSS_WEIGHT,
-            entropy_weight=self.train_config.ENTROPY_BONUS_WEIGHT,
-        )
-        if self.device.type == "cuda":
-            if self._grad_seed is None:
-                self._grad_seed = torch.ones((), dtype=torch.float32, device=self.device)
-            out.total.backward(self._grad_seed.to(out.total.dtype))  # a kept 1.0 instead of a fill launch per step
-        else:
-            out.total.backward()
+            if prepacked:
+                core.release_packed_filters()
         if self.flat is not None:
             self.flat.gather_grads()
         return out

@@ -928,6 +928,40 @@ def test_direct_conv_weight_gradient_matches_torch(cin, cout, batch, h, w):
     assert err < 2e-5
 
 
+def test_prepacked_filters_equal_the_per_layer_packing_and_are_released():
+    """AlphaTriangleNet.prepack_filters (one launch for all direct convolutions) gives the planes conv3_pack gives layer by
+    layer, _ConvGemmCM uses them, and release_packed_filters leaves no stale copy behind."""
+    from alphatriangle_amd.models.model import AlphaTriangleNet, GemmConv2d
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(101)
+    dev = torch.device("cuda")
+    net = AlphaTriangleNet(ModelConfig(), EnvConfig()).to(dev).train()
+    net.prepack_filters()
+    n = 0
+    for m in net.modules():
+        if isinstance(m, GemmConv2d) and hasattr(m.weight, "_atri_packed"):
+            for dgrad, planes in m.weight._atri_packed.items():
+                assert torch.equal(planes, hip_learner.conv3_pack(m.weight, dgrad)), (m, dgrad)
+                n += 1
+    assert n == 11, n  # 64 -> 128 and four 128 -> 128 layers in both forms, 32 -> 64 forward only
+    grid = torch.randint(-1, 2, (8, 1, 8, 15), device=dev).float()
+    other = torch.rand(8, 30, device=dev)
+    pl_a, vl_a = net(grid, other)
+    net.release_packed_filters()
+    assert not any(hasattr(p, "_atri_packed") for p in net.parameters())
+    for m in net.modules():  # same batch statistics for the second pass
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.momentum = 0.0
+    torch.manual_seed(5)
+    pl_b, vl_b = net(grid, other)
+    torch.manual_seed(5)
+    net.prepack_filters()
+    pl_c, vl_c = net(grid, other)
+    net.release_packed_filters()
+    assert torch.equal(pl_b, pl_c) and torch.equal(vl_b, vl_c)
+
+
 def test_conv_layer_on_the_direct_kernel_trains_like_the_gemm_lowered_layer():
     """_ConvGemmCM with DIRECT_CONV on and off: same output, input gradient and weight gradient."""
     import alphatriangle_amd.models.model as model_mod
