@@ -7,6 +7,19 @@
 
 namespace atrihip {
 namespace splittf {
+// Softmax without the row maximum ("free" pass): p = exp2(score + kFreeShift), accepted when every row sum of the wave lies in
+// (kFreeLo, kFreeHi); otherwise the wave repeats its tiles with the maximum subtracted.  bf16 pairs keep fp32's exponent
+// range, so the window only excludes overflow, total underflow and NaN.  fp16 pairs need every probability below 65504
+// (row sum < 2^15) and the row sum large enough that fp16's absolute resolution (2^-25 for the lo part) stays below
+// 2^-22 of it (row sum > 2^4); the shift of 3 centres that window on rows of ~100 comparable scores.  The safe pass
+// scales its probabilities by 2^kSafeShift for the same reason (largest term 16 instead of 1).
+constexpr float kFreeShift = kSplitF16 ? 3.0f : 0.0f;
+constexpr float kFreeLo = kSplitF16 ? 0x1p4f : 0x1p-100f;
+constexpr float kFreeHi = kSplitF16 ? 0x1p15f : 0x1p100f;
+constexpr float kSafeShift = kSplitF16 ? 4.0f : 0.0f;
+// A wave whose free pass was rejected this many times in one launch goes straight to the safe pass for its remaining
+// samples: weights that produce large scores cost a bounded number of repeated passes.
+constexpr int kFreeStrikes = 2;
 constexpr int kDs = 128;
 constexpr int kStrideS = 288;                  // bytes per token row of a 16-bit plane
 constexpr int kPlane = 128 * kStrideS;         // 36,864

@@ -113,11 +113,11 @@ __device__ __forceinline__ bool attention_tiles(const short8 (&qh)[4], const sho
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        s[kt][j] = __builtin_amdgcn_exp2f(SAFE ? s[kt][j] - m : s[kt][j]);
+        s[kt][j] = __builtin_amdgcn_exp2f(SAFE ? s[kt][j] - m + kSafeShift : s[kt][j] + kFreeShift);
         sum += s[kt][j];
       }
     sum = quad_row_sum(sum);
-    if (!SAFE) suspect |= !(sum > 7.9e-31f && sum < 1.2e30f);  // outside [2^-100, 2^100] or NaN
+    if (!SAFE) suspect |= !(sum > kFreeLo && sum < kFreeHi);  // outside the window of the operand format, or NaN
     float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
     ln_finish(first, A, a.eps1, tid);
   }
   int iter = 0;
+  int strikes = 0;  // rejected free softmax passes of this wave (wave-uniform)
   for (int b = blockIdx.x; b < nB; b += gridDim.x, ++iter) {
   // Everything below derives from a thread index the optimiser cannot see through: hoisting the sample-invariant
   // bias loads and addresses out of the loop would cost more registers than the kernel has.
@@ -267,23 +268,24 @@ __global__ __launch_bounds__(512, 2) void encoder_layer_split_kernel(SplitEncArg
   {
     const short8* kimg = reinterpret_cast<const short8*>(Bq) + (size_t)(cb * 8) * 2 * 64 + lane;
     const WRef wo = wref(a.wo, a.lo_o, frag);
-    if constexpr (kSplitF16) {
-      // fp16 operands: the probabilities have to stay within fp16's range, so the row maximum is always subtracted
-      if (HW > 112) {
-        (void)attention_tiles<true, true>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
-      } else {
-        (void)attention_tiles<true, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
-      }
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) load_wslice(w, kc, wo);  // the max-free pass starts these loads itself
-    } else {
+    bool need_safe = strikes >= kFreeStrikes, free_ran = false;
+    if (!need_safe) {
       bool suspect;
       if (HW > 112) {
         suspect = attention_tiles<false, true>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
       } else {
         suspect = attention_tiles<false, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
       }
-      if (__builtin_amdgcn_ballot_w64(suspect) != 0) (void)attention_tiles<true, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
+      free_ran = true;
+      need_safe = __builtin_amdgcn_ballot_w64(suspect) != 0;
+      if (need_safe) ++strikes;
+    }
+    if (need_safe) {
+      (void)attention_tiles<true, false>(qh, ql, vth, vtl, kimg, A, HW, tile0, cb, q4, l15, w, wo);
+      if (!free_ran) {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) load_wslice(w, kc, wo);  // the free pass starts these loads itself
+      }
     }
   }
   ATRI_PHASE(6);

@@ -134,11 +134,11 @@ __device__ __forceinline__ bool qa_tiles(const short8* kimg, const short8* vimg,
     for (int kt = 0; kt < 16; ++kt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        st[kt][j] = __builtin_amdgcn_exp2f(SAFE ? st[kt][j] - m : st[kt][j]);  // log2 units
+        st[kt][j] = __builtin_amdgcn_exp2f(SAFE ? st[kt][j] - m + kSafeShift : st[kt][j] + kFreeShift);  // log2 units
         sum += st[kt][j];
       }
     sum = quad_row_sum(sum);
-    if (!SAFE) suspect |= !(sum > 0x1p-100f && sum < 0x1p100f);  // overflow, total underflow or NaN
+    if (!SAFE) suspect |= !(sum > kFreeLo && sum < kFreeHi);  // outside the window of the operand format, or NaN
     // O^T = V^T P^T over eight blocks of 32 keys
     float4v o0 = (float4v){0.f, 0.f, 0.f, 0.f}, o1 = (float4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_split_kernel(SplitQkvAttnArgs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // biases and the first head's weights are in LDS
 
+  int strikes = 0;  // rejected free softmax passes of this wave (wave-uniform)
   for (int b = blockIdx.x; b < nB; b += gridDim.x) {
     const float* xg = a.x + (size_t)b * HW * kDs;
     // ---- this wave's 32 token rows -> LayerNorm in registers -> (hi, lo) operand fragments for all four heads.
@@ -294,15 +295,16 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_split_kernel(SplitQkvAttnArgs
         touch = xnext[(size_t)r * kDs + (lane & 1) * 32] + xnext[(size_t)r * kDs + 64 + (lane & 1) * 32];
       }
       float* og = a.att + (size_t)b * HW * kDs + head * 32 + q4 * 8;
-      // Softmax is shift invariant and the (hi, lo) split keeps fp32's exponent range, so the fast pass skips the row
-      // maximum and checks the denominators instead: a wave that saw one outside [2^-100, 2^100] (overflow, total
-      // underflow, NaN) repeats its tiles with the maximum subtracted and overwrites its outputs.
-      if constexpr (kSplitF16) {  // fp16 operands: probabilities must stay within fp16's range, always subtract the maximum
-        (void)qa_tiles<KTF, true>(kimg, vimg, Qh, Ql, og, HW, oct, q4, l15);
-      } else {
+      // Softmax is shift invariant, so the fast pass skips the row maximum and checks the denominators instead: a wave
+      // that saw one outside the window of the operand format (split_tf_common.hpp) repeats its tiles with the maximum
+      // subtracted and overwrites its outputs; after kFreeStrikes rejections it stops trying for the rest of the launch.
+      bool need_safe = strikes >= kFreeStrikes;
+      if (!need_safe) {
         const bool suspect = qa_tiles<KTF, false>(kimg, vimg, Qh, Ql, og, HW, oct, q4, l15);
-        if (__builtin_amdgcn_ballot_w64(suspect) != 0) (void)qa_tiles<KTF, true>(kimg, vimg, Qh, Ql, og, HW, oct, q4, l15);
+        need_safe = __builtin_amdgcn_ballot_w64(suspect) != 0;
+        if (need_safe) ++strikes;
       }
+      if (need_safe) (void)qa_tiles<KTF, true>(kimg, vimg, Qh, Ql, og, HW, oct, q4, l15);
       asm volatile("" ::"v"(touch));  // keeps the touch loads alive
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // every wave is done with the images; the next head's weights are in LDS
