@@ -73,6 +73,46 @@ def test_fp32_engine_stays_within_an_order_of_magnitude_of_pytorch_fp32_rounding
     assert (logits.argmax(1) == ref64_l.argmax(1)).float().mean().item() >= 0.99
 
 
+@pytest.mark.parametrize("preset,qscale", [("default", 6.0), ("default", 60.0), ("large", 6.0), ("large", 60.0)])
+def test_fp32_engine_softmax_outside_the_free_window_takes_the_safe_pass(preset, qscale):
+    """Query projections scaled so that the attention scores leave the row-sum window of the softmax pass that skips the row
+    maximum (all rows at x 60, some at x 6): those waves must repeat their tiles with the maximum subtracted - and stop
+    trying after two rejections - and the result has to stay as close to fp64 as with ordinary scores."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.presets import build_preset
+
+    torch.manual_seed(29)
+    dev = torch.device("cuda")
+    if preset == "default":
+        env, mc = EnvConfig(), ModelConfig()
+    else:
+        env, mc, _, _, _ = build_preset("large")
+    net = NeuralNetwork(mc, env, TrainConfig(DEVICE="cuda"), dev, inference_dtype="fp32")
+    assert net.engine is not None and net.engine.dtype == "fp32"
+    _randomise_norm_layers(net._orig_model)
+    d = mc.TRANSFORMER_DIM
+    with torch.no_grad():
+        for layer in net._orig_model.transformer_body.layers:
+            layer.self_attn.in_proj_weight[:d] *= qscale
+            layer.self_attn.in_proj_bias[:d] *= qscale
+    net.sync_inference_weights()
+    batch = 600 if preset == "default" else 40  # more samples than persistent workgroups: later samples run after the strikes
+    grid = torch.randint(-1, 2, (batch, 1, env.ROWS, env.COLS), device=dev).float()
+    other = torch.rand(batch, mc.OTHER_NN_INPUT_FEATURES_DIM, device=dev)
+    net._orig_model.eval()
+    with torch.no_grad():
+        ref32_l, _ = net._orig_model(grid, other)
+        ref64_l, _ = copy.deepcopy(net._orig_model).double()(grid.double(), other.double())
+    logits, value = net.evaluate_features(grid, other)
+    torch.cuda.synchronize()
+    assert torch.isfinite(logits).all() and torch.isfinite(value).all()
+    scale = max(ref64_l.abs().max().item(), 1.0)
+    eng_err = (logits.double() - ref64_l).abs().max().item()
+    t32_err = (ref32_l.double() - ref64_l).abs().max().item()
+    print(f"[{preset} x{qscale}] logits: engine {eng_err:.3e}, torch fp32 {t32_err:.3e} (scale {scale:.2f})")
+    assert eng_err < 2e-5 * scale and eng_err < 5 * max(t32_err, 5e-7), (eng_err, t32_err)
+
+
 def _fp64_stages(model: torch.nn.Module, grid: torch.Tensor) -> list[tuple[str, torch.Tensor]]:
     """Activation rows [B, HW, 128] of an fp64 copy of the module after the stem, every residual block and every encoder
     layer, named like the entries of ``InferenceEngine.trace``."""
