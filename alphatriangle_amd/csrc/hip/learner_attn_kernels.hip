@@ -34,6 +34,7 @@ struct AttnArgs {
   float scale;                      // 1 / sqrt(32)
   unsigned thresh;                  // an element is dropped when its hash is below this
   float keep_scale;                 // 1 / (1 - p)
+  int batch_major;                  // rows are sample * L + token instead of token * B + sample (a sample's rows contiguous)
 };
 
 namespace {
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int l15 = lane & 15, q4 = lane >> 4;
   const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
   const int D = a.H * 32, L = a.L;
-  const size_t pitch = (size_t)a.B * 3 * D;
-  const T* qbase = reinterpret_cast<const T*>(a.qkv) + (size_t)b * 3 * D + h * 32;
+  const size_t pitch = a.batch_major ? (size_t)3 * D : (size_t)a.B * 3 * D;
+  const T* qbase = reinterpret_cast<const T*>(a.qkv) + (a.batch_major ? (size_t)b * L * 3 * D : (size_t)b * 3 * D) + h * 32;
   build_row_image<T, P, KT>(kimg, qbase + D, pitch, L, 1.0f, wave, lane);
   build_transposed_image<T, P, KT>(vimg, qbase + 2 * D, pitch, L, 1.0f, wave, lane);
   unsigned s0 = 0, s1 = 0;
@@ -170,8 +171,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   }
   __syncthreads();
 
-  T* obase = reinterpret_cast<T*>(a.out) + (size_t)b * D + h * 32;
-  const size_t opitch = (size_t)a.B * D;
+  T* obase = reinterpret_cast<T*>(a.out) + (a.batch_major ? (size_t)b * L * D : (size_t)b * D) + h * 32;
+  const size_t opitch = a.batch_major ? (size_t)D : (size_t)a.B * D;
   for (int qt = wave; qt < KT; qt += 4) {
     if (qt * 16 >= L) break;  // wave-uniform
     const int query = qt * 16 + l15;
@@ -248,10 +249,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const int l15 = lane & 15, q4 = lane >> 4;
   const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
   const int D = a.H * 32, L = a.L;
-  const size_t pitch = (size_t)a.B * 3 * D, opitch = (size_t)a.B * D;
-  const T* qbase = reinterpret_cast<const T*>(a.qkv) + (size_t)b * 3 * D + h * 32;
-  const T* dobase = reinterpret_cast<const T*>(a.dout) + (size_t)b * D + h * 32;
-  T* gbase = reinterpret_cast<T*>(a.out) + (size_t)b * 3 * D + h * 32;
+  const size_t pitch = a.batch_major ? (size_t)3 * D : (size_t)a.B * 3 * D, opitch = a.batch_major ? (size_t)D : (size_t)a.B * D;
+  const size_t q_off = (a.batch_major ? (size_t)b * L * 3 * D : (size_t)b * 3 * D) + h * 32;
+  const T* qbase = reinterpret_cast<const T*>(a.qkv) + q_off;
+  const T* dobase = reinterpret_cast<const T*>(a.dout) + (a.batch_major ? (size_t)b * L * D : (size_t)b * D) + h * 32;
+  T* gbase = reinterpret_cast<T*>(a.out) + q_off;
   const float s2 = a.scale * kLog2e;
   unsigned s0 = 0, s1 = 0;
   if (a.thresh) {
@@ -440,21 +442,34 @@ int atri_attn_lse_pitch(int L) { return L > 128 ? 256 : 128; }
 
 // ctx[L*B, 32H] = dropout(softmax(Q K^T / sqrt(32))) V per (sample, head) from packed qkv [L*B, 96H]; lse receives the
 // log2-domain log-sum-exp of every query ([B*H, atri_attn_lse_pitch(L)] floats).
-int atri_attn_fwd(const void* qkv, int is_bf16, void* ctx, float* lse, const void* seed, int L, int B, int H, float p_drop,
-                  hipStream_t stream) {
+// batch_major: qkv / ctx rows are sample * L + token ([B, L, ...]) instead of token * B + sample ([L, B, ...]).
+int atri_attn_fwd_layout(const void* qkv, int is_bf16, void* ctx, float* lse, const void* seed, int L, int B, int H, float p_drop,
+                         int batch_major, hipStream_t stream) {
   AttnArgs a{};
   const int rc = fill_args(a, qkv, nullptr, ctx, lse, seed, L, B, H, p_drop);
   if (rc) return rc;
+  a.batch_major = batch_major ? 1 : 0;
   return dispatch_attn(a, is_bf16, false, stream);
 }
 
+int atri_attn_fwd(const void* qkv, int is_bf16, void* ctx, float* lse, const void* seed, int L, int B, int H, float p_drop,
+                  hipStream_t stream) {
+  return atri_attn_fwd_layout(qkv, is_bf16, ctx, lse, seed, L, B, H, p_drop, 0, stream);
+}
+
 // dqkv[L*B, 96H] from qkv, the gradient of ctx and the forward's lse / seed / p_drop.  Every element of dqkv is written.
-int atri_attn_bwd(const void* qkv, const void* dctx, int is_bf16, void* dqkv, float* lse, const void* seed, int L, int B, int H,
-                  float p_drop, hipStream_t stream) {
+int atri_attn_bwd_layout(const void* qkv, const void* dctx, int is_bf16, void* dqkv, float* lse, const void* seed, int L, int B, int H,
+                         float p_drop, int batch_major, hipStream_t stream) {
   AttnArgs a{};
   const int rc = fill_args(a, qkv, dctx, dqkv, lse, seed, L, B, H, p_drop);
   if (rc) return rc;
+  a.batch_major = batch_major ? 1 : 0;
   return dispatch_attn(a, is_bf16, true, stream);
+}
+
+int atri_attn_bwd(const void* qkv, const void* dctx, int is_bf16, void* dqkv, float* lse, const void* seed, int L, int B, int H,
+                  float p_drop, hipStream_t stream) {
+  return atri_attn_bwd_layout(qkv, dctx, is_bf16, dqkv, lse, seed, L, B, H, p_drop, 0, stream);
 }
 
 }  // extern "C"

@@ -600,31 +600,38 @@ def _lse_pitch(seq: int) -> int:
     return 256 if seq > 128 else 128
 
 
-def attention_forward(qkv: torch.Tensor, heads: int, p_drop: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None]:
+def attention_forward(qkv: torch.Tensor, heads: int, p_drop: float, batch_major: bool = False) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None]:
     """``dropout(softmax(Q K^T / sqrt(32))) V`` per (sample, head) in one launch (``attn_fwd_kernel``).
 
-    Returns ``(ctx [L, B, 32 * heads], lse, seed)``: ``lse`` (log2-domain log-sum-exp per query) and ``seed`` (the dropout
-    seed, drawn from torch's generator so that ``torch.manual_seed`` governs it and a captured step draws a new one on
-    every replay) are what :func:`attention_backward` needs next to ``qkv``.
+    ``qkv`` is ``[L, B, 3 * 32 * heads]`` or, with ``batch_major``, ``[B, L, 3 * 32 * heads]`` (a sample's rows contiguous).
+    Returns ``(ctx, lse, seed)`` with ``ctx`` in the layout of ``qkv``: ``lse`` (log2-domain log-sum-exp per query) and
+    ``seed`` (the dropout seed, drawn from torch's generator so that ``torch.manual_seed`` governs it and a captured step
+    draws a new one on every replay) are what :func:`attention_backward` needs next to ``qkv``.
     """
     qkv = qkv.contiguous()
-    seq, batch, width = qkv.shape
-    ctx = torch.empty(seq, batch, width // 3, dtype=qkv.dtype, device=qkv.device)
+    if batch_major:
+        batch, seq, width = qkv.shape
+    else:
+        seq, batch, width = qkv.shape
+    ctx = torch.empty(*qkv.shape[:2], width // 3, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(batch * heads, _lse_pitch(seq), dtype=torch.float32, device=qkv.device)
     seed = _drop_seed(qkv.device) if p_drop > 0 else None
-    hb.call("atri_attn_fwd", hb.ptr(qkv), hb.i32(1 if qkv.dtype == torch.bfloat16 else 0), hb.ptr(ctx), hb.ptr(lse), hb.ptr(seed),
-            hb.i32(seq), hb.i32(batch), hb.i32(heads), hb.f32(p_drop))
+    hb.call("atri_attn_fwd_layout", hb.ptr(qkv), hb.i32(1 if qkv.dtype == torch.bfloat16 else 0), hb.ptr(ctx), hb.ptr(lse), hb.ptr(seed),
+            hb.i32(seq), hb.i32(batch), hb.i32(heads), hb.f32(p_drop), hb.i32(1 if batch_major else 0))
     return ctx, lse, seed
 
 
 def attention_backward(qkv: torch.Tensor, dctx: torch.Tensor, lse: torch.Tensor, seed: torch.Tensor | None, heads: int,
-                       p_drop: float) -> torch.Tensor:
+                       p_drop: float, batch_major: bool = False) -> torch.Tensor:
     """Gradient of the packed ``qkv`` rows for :func:`attention_forward` in one launch (``attn_bwd_kernel``)."""
-    seq, batch, _ = qkv.shape
+    if batch_major:
+        batch, seq, _ = qkv.shape
+    else:
+        seq, batch, _ = qkv.shape
     dctx = dctx.to(qkv.dtype).contiguous()
     dqkv = torch.empty_like(qkv)
-    hb.call("atri_attn_bwd", hb.ptr(qkv), hb.ptr(dctx), hb.i32(1 if qkv.dtype == torch.bfloat16 else 0), hb.ptr(dqkv), hb.ptr(lse),
-            hb.ptr(seed), hb.i32(seq), hb.i32(batch), hb.i32(heads), hb.f32(p_drop))
+    hb.call("atri_attn_bwd_layout", hb.ptr(qkv), hb.ptr(dctx), hb.i32(1 if qkv.dtype == torch.bfloat16 else 0), hb.ptr(dqkv), hb.ptr(lse),
+            hb.ptr(seed), hb.i32(seq), hb.i32(batch), hb.i32(heads), hb.f32(p_drop), hb.i32(1 if batch_major else 0))
     return dqkv
 
 

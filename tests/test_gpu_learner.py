@@ -513,6 +513,27 @@ def test_fused_attention_kernels_match_torch(dtype, seq, batch, heads, p):
     assert (lse.view(batch, heads, -1)[:, :, :seq].double() - lse_ref).abs().max().item() < (1e-4 if dtype == torch.float32 else 5e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("seq,batch,heads", [(45, 5, 2), (120, 16, 4), (252, 3, 4)])
+def test_fused_attention_batch_major_rows_equal_token_major_rows(dtype, seq, batch, heads):
+    """The ``batch_major`` row order (``[B, L, ...]``) is the same arithmetic on the same (sample, head) slices: bitwise equal."""
+    from alphatriangle_amd.ops import hip_learner
+
+    torch.manual_seed(43)
+    dev = torch.device("cuda")
+    qkv = torch.randn(seq, batch, 96 * heads, device=dev).to(dtype)
+    w = torch.randn(seq, batch, 32 * heads, device=dev).to(dtype)
+    ctx, lse, seed = hip_learner.attention_forward(qkv, heads, 0.0)
+    dqkv = hip_learner.attention_backward(qkv, w, lse, seed, heads, 0.0)
+    qkv_b, w_b = qkv.transpose(0, 1).contiguous(), w.transpose(0, 1).contiguous()
+    ctx_b, lse_b, seed_b = hip_learner.attention_forward(qkv_b, heads, 0.0, batch_major=True)
+    dqkv_b = hip_learner.attention_backward(qkv_b, w_b, lse_b, seed_b, heads, 0.0, batch_major=True)
+    torch.cuda.synchronize()
+    assert ctx_b.shape == (batch, seq, 32 * heads) and dqkv_b.shape == qkv_b.shape
+    assert torch.equal(ctx_b, ctx.transpose(0, 1)) and torch.equal(dqkv_b, dqkv.transpose(0, 1))
+    assert torch.equal(lse_b[:, :seq], lse[:, :seq])
+
+
 def test_fused_attention_draws_a_new_mask_on_every_graph_replay():
     """Captured forward + backward replayed three times: every replay equals an eager run with the seed it drew."""
     from alphatriangle_amd.ops import hip_learner
