@@ -2,6 +2,8 @@
 
 * ``_atri_host``  - host C++ runtime (pybind11, g++): game engine, features,
   host tree search, sum tree, metric ring.
+* ``_atri_host_wide`` - the same sources compiled with 16 occupancy words per
+  game state: boards of 257 - 1024 cells (host engine only).
 * ``libatri_hip`` - HIP/CDNA4 kernels for gfx950 (hipcc): batched game + tree
   engine, inference network, replay and learner kernels.  Exposed with a C ABI
   and loaded through ctypes after ``import torch`` so that it binds to the same
@@ -22,7 +24,10 @@ from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
-HOST_SO = PKG_DIR / ("_atri_host" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+_EXT = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+HOST_SO = PKG_DIR / ("_atri_host" + _EXT)
+HOST_WIDE_SO = PKG_DIR / ("_atri_host_wide" + _EXT)
+WIDE_WORDS = 16  # 64 cells per word: boards of up to 1024 cells
 HIP_SO = PKG_DIR / "libatri_hip.so"
 
 HIP_FLAGS = [
@@ -60,32 +65,35 @@ def _all_headers() -> list[Path]:
 
 
 def build_host(force: bool = False, verbose: bool = True) -> Path:
+    """Build both host modules (the 256-cell one and the wide one) when they are older than their sources."""
     import pybind11
 
     srcs = host_sources()
     deps = srcs + _all_headers() + [Path(__file__)]
-    if not force and _newer(HOST_SO, deps):
-        return HOST_SO
-    cxx = os.environ.get("CXX", "g++")
-    cmd = [
-        cxx,
-        "-O2",
-        "-std=c++17",
-        "-fPIC",
-        "-shared",
-        "-ffp-contract=off",
-        "-fvisibility=hidden",
-        "-Wall",
-        "-Wno-unused-function",
-        f"-I{pybind11.get_include()}",
-        f"-I{sysconfig.get_paths()['include']}",
-        *[str(s) for s in srcs],
-        "-o",
-        str(HOST_SO),
-    ]
-    if verbose:
-        print("[build_native] host:", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    for target, defines in ((HOST_SO, []), (HOST_WIDE_SO, [f"-DATRI_MAX_WORDS={WIDE_WORDS}", "-DATRI_HOST_MODULE=_atri_host_wide"])):
+        if not force and _newer(target, deps):
+            continue
+        cxx = os.environ.get("CXX", "g++")
+        cmd = [
+            cxx,
+            "-O2",
+            "-std=c++17",
+            "-fPIC",
+            "-shared",
+            "-ffp-contract=off",
+            "-fvisibility=hidden",
+            "-Wall",
+            "-Wno-unused-function",
+            *defines,
+            f"-I{pybind11.get_include()}",
+            f"-I{sysconfig.get_paths()['include']}",
+            *[str(s) for s in srcs],
+            "-o",
+            str(target),
+        ]
+        if verbose:
+            print("[build_native] host:", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return HOST_SO
 
 
@@ -123,8 +131,9 @@ def build_hip(force: bool = False, verbose: bool = True) -> Path:
 SANITIZERS = {"address": "address,undefined", "thread": "thread"}
 
 
-def build_selftest(kind: str = "address", verbose: bool = True) -> Path:
-    """Build the stand-alone host-runtime exerciser with ``-fsanitize=<kind>`` (address+undefined or thread).
+def build_selftest(kind: str = "address", verbose: bool = True, wide: bool = False) -> Path:
+    """Build the stand-alone host-runtime exerciser with ``-fsanitize=<kind>`` (address+undefined or thread);
+    ``wide`` compiles the 16-word game state of ``_atri_host_wide`` and adds a 600-cell board to the run.
 
     The sanitized process contains only the C++ runtime (engine, search, sum tree, metric ring), so no
     Python allocator noise and no preloading is needed; ``tests/test_host_sanitizers.py`` runs the binaries.
@@ -133,11 +142,11 @@ def build_selftest(kind: str = "address", verbose: bool = True) -> Path:
         raise ValueError(f"unknown sanitizer '{kind}' (choose from {sorted(SANITIZERS)})")
     out_dir = PKG_DIR / "build" / "selftest"
     out_dir.mkdir(parents=True, exist_ok=True)
-    out = out_dir / f"host_selftest_{kind}"
+    out = out_dir / (f"host_selftest_{kind}" + ("_wide" if wide else ""))
     src = CSRC / "selftest" / "host_selftest.cpp"
     cmd = [
         os.environ.get("CXX", "g++"), "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-omit-frame-pointer",
-        f"-fsanitize={SANITIZERS[kind]}", str(src), "-o", str(out), "-pthread",
+        f"-fsanitize={SANITIZERS[kind]}", *([f"-DATRI_MAX_WORDS={WIDE_WORDS}"] if wide else []), str(src), "-o", str(out), "-pthread",
     ]
     if verbose:
         print("[build_native] selftest:", " ".join(cmd), flush=True)

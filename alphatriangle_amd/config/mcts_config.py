@@ -36,11 +36,12 @@ class AlphaTriangleMCTSConfig(BaseModel):
     def capacity(self) -> int:
         return int(self.tree_capacity or (2 * self.max_simulations + 2))
 
-    def to_search_params(self, leaf_batch: int | None = None):
-        """Parameter block for the native searches (host C++ and HIP)."""
+    def to_search_params(self, leaf_batch: int | None = None, module=None):
+        """Parameter block for the native searches (host C++ and HIP).  ``module`` names the host build that will
+        consume it (``native.host_of(geometry)``: the wide build for boards above 256 cells); default: the 256-cell one."""
         from .. import native
 
-        return native.host().SearchParams(
+        return (module or native.host()).SearchParams(
             max_simulations=self.max_simulations,
             max_depth=self.max_depth,
             cpuct=self.cpuct,

@@ -25,9 +25,19 @@
 #pragma clang fp contract(off)
 #endif
 
+// Occupancy words of a game state.  4 (256 cells, the 64-byte state of the device engine) unless the build says otherwise:
+// the wide host module is the same code compiled with 16 words (1024 cells).  A wide build lives in a namespace of its
+// own, so that both host modules can be loaded into one process without sharing a single type.
+#ifndef ATRI_MAX_WORDS
+#define ATRI_MAX_WORDS 4
+#endif
+#if ATRI_MAX_WORDS != 4
+#define atri atri_wide
+#endif
+
 namespace atri {
 
-constexpr int kMaxWords = 4;   // 4 x 64 = up to 256 grid cells
+constexpr int kMaxWords = ATRI_MAX_WORDS;   // 64 grid cells per word
 constexpr int kMaxSlots = 4;
 constexpr int kMaxTris = 5;
 constexpr int kShapeFeat = 7;
@@ -48,7 +58,7 @@ struct GeomView {
   const uint8_t* tmpl_ntris;   // [n_templates]
 };
 
-// Compact game state: 64 bytes, one per tree node in HBM.
+// Compact game state: 64 bytes with four occupancy words, one per tree node in HBM.
 struct State {
   uint64_t occ[kMaxWords];
   uint64_t rng;
@@ -60,7 +70,7 @@ struct State {
   uint8_t pad0;
   int32_t tris_cleared_total;
 };
-static_assert(sizeof(State) == 64, "State must stay 64 bytes");
+static_assert(sizeof(State) == 32 + 8 * kMaxWords, "State must stay 32 bytes + the occupancy words (64 bytes on the device)");
 
 // ---------------------------------------------------------------- RNG
 // splitmix64: counter based, identical on host and device.

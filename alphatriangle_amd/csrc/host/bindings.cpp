@@ -25,7 +25,15 @@
 namespace py = pybind11;
 using namespace atri;
 
-namespace {
+// Module name: `_atri_host` (256-cell boards, the state layout of the device engine) or, compiled with
+// -DATRI_MAX_WORDS=16 -DATRI_HOST_MODULE=_atri_host_wide, the wide module for boards of up to 1024 cells.
+#ifndef ATRI_HOST_MODULE
+#define ATRI_HOST_MODULE _atri_host
+#endif
+
+// The binding helpers live in the core's namespace (not an anonymous one): the wide build renames that namespace, which
+// keeps every bound C++ type of the two modules distinct in pybind11's process-wide registry.
+namespace atri {
 
 struct PyGeometry {
   std::shared_ptr<Geometry> g;
@@ -142,9 +150,9 @@ struct PyTree {
   }
 };
 
-}  // namespace
+}  // namespace atri
 
-PYBIND11_MODULE(_atri_host, m) {
+PYBIND11_MODULE(ATRI_HOST_MODULE, m) {
   m.doc() = "Host runtime of alphatriangle_amd (game engine, features, tree search, sum tree, metric ring)";
   m.attr("MAX_WORDS") = kMaxWords;
   m.attr("MAX_SLOTS") = kMaxSlots;
@@ -315,7 +323,7 @@ PYBIND11_MODULE(_atri_host, m) {
       .def("unpack",
            [](PyState& s, py::bytes b) {
              std::string raw = b;
-             if (raw.size() != sizeof(State)) throw std::invalid_argument("packed state must be 64 bytes");
+             if (raw.size() != sizeof(State)) throw std::invalid_argument("packed state must be " + std::to_string(sizeof(State)) + " bytes");
              std::memcpy(&s.st, raw.data(), sizeof(State));
              for (int c = 0; c < s.g->cells; ++c) s.color[c] = cell_bit(s.st.occ, c) ? (s.color[c] < 0 ? 0 : s.color[c]) : -1;
            })

@@ -138,7 +138,7 @@ class Geometry {
   void build() {
     if (p.rows <= 0 || p.cols <= 0) throw std::invalid_argument("ROWS and COLS must be positive");
     cells = p.rows * p.cols;
-    if (cells > 64 * kMaxWords) throw std::invalid_argument("grid larger than 256 cells is not supported");
+    if (cells > 64 * kMaxWords) throw std::invalid_argument("grid larger than " + std::to_string(64 * kMaxWords) + " cells is not supported by this build of the host engine");
     if (p.slots < 1 || p.slots > kMaxSlots) throw std::invalid_argument("NUM_SHAPE_SLOTS must be in 1..4");
     if ((int)p.playable_range.size() != p.rows)
       throw std::invalid_argument("PLAYABLE_RANGE_PER_ROW needs one (start, end) pair per row");

@@ -167,6 +167,17 @@ int main() {
   auto geom = std::make_shared<const Geometry>(default_params());
   test_engine(*geom);
   test_search(geom);
+  if (kMaxWords > 4) {
+    // the wide build (-DATRI_MAX_WORDS=16): a 20 x 30 board, ten occupancy words
+    EnvParams p;
+    p.rows = 20;
+    p.cols = 30;
+    p.playable_range.assign(20, {1, 29});
+    auto wide = std::make_shared<const Geometry>(p);
+    CHECK(wide->view().cells == 600 && wide->view().nwords == 10);
+    test_engine(*wide);
+    test_search(wide);
+  }
   test_sumtree();
   test_ring();
   std::puts("host selftest: ok");

@@ -29,7 +29,7 @@ def get_geometry(env_config: EnvConfig):
     with _geom_lock:
         geom = _geom_cache.get(key)
         if geom is None:
-            geom = native.host().Geometry(
+            geom = native.host(env_config.ROWS * env_config.COLS).Geometry(
                 rows=env_config.ROWS,
                 cols=env_config.COLS,
                 playable_range=[tuple(r) for r in env_config.PLAYABLE_RANGE_PER_ROW],
@@ -82,12 +82,13 @@ class Shape:
 
 
 class GameState:
-    """One game of the triangle puzzle (thin wrapper over the native 64-byte state)."""
+    """One game of the triangle puzzle (thin wrapper over the native state: 64 bytes up to 256 cells, the wide host
+    build's 160 bytes above)."""
 
     def __init__(self, config: EnvConfig | None = None, initial_seed: int = 0, *, _core: Any = None):
         self.env_config: EnvConfig = config if config is not None else EnvConfig()
         self._geom = get_geometry(self.env_config)
-        self._core = _core if _core is not None else native.host().CoreState(self._geom, int(initial_seed) & (2**64 - 1))
+        self._core = _core if _core is not None else native.host_of(self._geom).CoreState(self._geom, int(initial_seed) & (2**64 - 1))
 
     # -- construction helpers
     @classmethod
@@ -106,7 +107,7 @@ class GameState:
         return GameState(self.env_config, _core=self._core.copy())
 
     def reset(self, seed: int = 0) -> None:
-        self._core = native.host().CoreState(self._geom, int(seed) & (2**64 - 1))
+        self._core = native.host_of(self._geom).CoreState(self._geom, int(seed) & (2**64 - 1))
 
     # -- rules
     def step(self, action: int) -> tuple[float, bool]:

@@ -121,7 +121,7 @@ def extract_state_features(game_state: GameState, model_config: ModelConfig) -> 
     """Return ``{"grid": (C,H,W) f32, "other_features": (D,) f32}`` for one state."""
     cfg = game_state.env_config
     _warn_dim_mismatch(8 * cfg.NUM_SHAPE_SLOTS + EXPLICIT_FEATURES_DIM, model_config.OTHER_NN_INPUT_FEATURES_DIM)
-    grid, other = native.host().extract_features(
+    grid, other = native.host_of(game_state.core).extract_features(
         game_state.core, model_config.GRID_INPUT_CHANNELS, model_config.OTHER_NN_INPUT_FEATURES_DIM
     )
     return {"grid": grid, "other_features": other}
@@ -131,8 +131,9 @@ def extract_features_batch(
     states: list[GameState], model_config: ModelConfig, rows: int, cols: int
 ) -> tuple[np.ndarray, np.ndarray]:
     """Batched extraction: ``(grid [n,C,H,W], other [n,D])``."""
-    return native.host().extract_features_batch(
-        [s.core if isinstance(s, GameState) else s for s in states],
+    cores = [s.core if isinstance(s, GameState) else s for s in states]
+    return (native.host_of(cores[0]) if cores else native.host(rows * cols)).extract_features_batch(
+        cores,
         model_config.GRID_INPUT_CHANNELS,
         model_config.OTHER_NN_INPUT_FEATURES_DIM,
         rows,

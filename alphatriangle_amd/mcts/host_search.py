@@ -82,8 +82,8 @@ def run_mcts(
     if handle is not None and handle.config_key == key and last_action is not None and last_action >= 0:
         reuse_action = int(last_action)
     else:
-        handle = TreeHandle(native.host().SearchTree(geom, config.capacity(), int(seed) & (2**63 - 1)), key)
-    params = config.to_search_params()
+        handle = TreeHandle(native.host_of(geom).SearchTree(geom, config.capacity(), int(seed) & (2**63 - 1)), key)
+    params = config.to_search_params(module=native.host_of(geom))
     evaluator = _make_evaluator(network_interface, root_state.env_config, geom.action_dim)
     visits = handle.tree.search(root_state.core, params, evaluator, reuse_action)
     nz = np.nonzero(visits)[0]

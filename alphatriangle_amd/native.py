@@ -1,7 +1,9 @@
-"""Loaders for the two in-tree native libraries.
+"""Loaders for the in-tree native libraries.
 
 ``host()`` returns the pybind11 module (built on demand with g++ when missing:
-it needs no GPU).  ``hip()`` returns the ctypes handle of the gfx950 kernel
+it needs no GPU); ``host(cells)`` returns the module whose game state holds a
+board of that many cells (the wide build above 256 cells), ``host_of(obj)`` the
+module a bound object came from.  ``hip()`` returns the ctypes handle of the gfx950 kernel
 library; it is never built implicitly on a GPU box and raises loudly when it is
 missing, so that GPU code paths cannot silently fall back to eager PyTorch.
 """
@@ -11,35 +13,54 @@ from __future__ import annotations
 import ctypes
 import os
 import importlib
+import sys
 import threading
 from pathlib import Path
 from types import ModuleType
 
 _PKG = Path(__file__).resolve().parent
 _lock = threading.Lock()
-_host_mod: ModuleType | None = None
+_host_mods: dict[str, ModuleType] = {}
 _hip_lib: ctypes.CDLL | None = None
+
+NARROW_CELLS = 256   # four 64-bit occupancy words: the 64-byte state shared with the device engine
+WIDE_CELLS = 1024    # sixteen words: the wide host module (host engine only)
 
 
 class NativeLibraryError(RuntimeError):
     """Raised when a required native library is missing or fails to load."""
 
 
-def host() -> ModuleType:
-    global _host_mod
-    if _host_mod is not None:
-        return _host_mod
+def _load_host(name: str) -> ModuleType:
+    mod = _host_mods.get(name)
+    if mod is not None:
+        return mod
     with _lock:
-        if _host_mod is None:
+        mod = _host_mods.get(name)
+        if mod is None:
             try:
-                _host_mod = importlib.import_module("alphatriangle_amd._atri_host")
+                mod = importlib.import_module(f"alphatriangle_amd.{name}")
             except ImportError:
                 from .build_native import build_host
 
                 build_host(verbose=False)
                 importlib.invalidate_caches()
-                _host_mod = importlib.import_module("alphatriangle_amd._atri_host")
-    return _host_mod
+                mod = importlib.import_module(f"alphatriangle_amd.{name}")
+            _host_mods[name] = mod
+    return mod
+
+
+def host(cells: int | None = None) -> ModuleType:
+    """The host runtime.  ``cells`` picks the build whose game state fits a board of that size; everything that does not
+    touch a game state (sum tree, metric ring) uses the default module."""
+    if cells is not None and cells > WIDE_CELLS:
+        raise NativeLibraryError(f"a board of {cells} cells exceeds the widest host engine build ({WIDE_CELLS} cells)")
+    return _load_host("_atri_host_wide" if cells is not None and cells > NARROW_CELLS else "_atri_host")
+
+
+def host_of(obj: object) -> ModuleType:
+    """The host module that created a bound object (geometry, state, tree): the two builds do not accept each other's."""
+    return sys.modules[type(obj).__module__]
 
 
 def hip_library_path() -> Path:

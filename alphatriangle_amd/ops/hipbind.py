@@ -199,6 +199,9 @@ class DeviceGeometry:
     """Geometry tables mirrored into HBM plus the by-value ``GeomView`` kernel argument."""
 
     def __init__(self, geom: Any, device: torch.device):
+        if geom.nwords > 4:
+            # the device engine's tree holds 64-byte states (four occupancy words); the wide host engine plays larger boards
+            raise ValueError(f"the HIP game / tree engine holds boards of up to 256 cells, this one has {geom.cells}")
         self.geom = geom
         self.device = device
 

@@ -34,6 +34,7 @@ reference's manager likewise notices a dead worker and carries on or stops
 from __future__ import annotations
 
 import datetime
+import importlib
 import logging
 import os
 from dataclasses import dataclass, field
@@ -321,6 +322,13 @@ def init_distributed(
         device = torch.device("cuda", local_rank % torch.cuda.device_count()) if torch.cuda.is_available() else torch.device("cpu")
     owns = False
     if not dist.is_initialized():
+        # torch.distributed.nn.functional declares `group=group.WORLD` in ten signatures.  torch imports it lazily (with
+        # torch._dynamo, on the first optimizer step); imported while a process group exists, those defaults pin the group
+        # for the life of the process, destroy_process_group() no longer ends its worker threads, and a gloo worker that
+        # drops the last reference of a tensor while the interpreter finalizes aborts the process ("terminate called
+        # without an active exception", exit code 134 after a complete run).  Imported here, the defaults hold None.
+        importlib.import_module("torch.distributed.nn.functional")
+
         kw: dict[str, Any] = {}
         if be == "nccl":
             kw["device_id"] = device

@@ -5,6 +5,8 @@
 * ``default`` - default grid, CNN + Transformer encoder, 400 simulations on GPU engines
   (the reference's own default of 64 simulations is kept for the cpu engine by ``reference``).
 * ``large``   - 12x21 grid, 8-layer Transformer, 800 simulations, HBM-sized replay.
+* ``huge``    - 20x30 grid (600 cells, above the 256 the device engine's 64-byte state holds): CNN network, 64
+  simulations, host workers on the wide build of the C++ engine, learner on the training device.
 * ``reference`` - every reference default untouched (64 simulations, 8 CPU workers).
 """
 
@@ -64,4 +66,9 @@ def build_preset(name: str) -> tuple[EnvConfig, ModelConfig, AlphaTriangleMCTSCo
             TrainConfig(BUFFER_CAPACITY=4_000_000, MIN_BUFFER_SIZE_TO_TRAIN=100_000),
             SystemConfig(GAMES_PER_GPU=2048, REPLAY_HBM_BUDGET_GB=128.0),
         )
-    raise ValueError(f"unknown preset '{name}' (choose tiny, cnn, default, large, reference)")
+    if name == "huge":
+        rows, cols = 20, 30
+        ranges = [(max(0, 4 - r, r - (rows - 5)), cols - max(0, 4 - r, r - (rows - 5))) for r in range(rows)]
+        env = EnvConfig(ROWS=rows, COLS=cols, PLAYABLE_RANGE_PER_ROW=ranges, NUM_SHAPE_SLOTS=3)
+        return env, ModelConfig.cnn_only(), AlphaTriangleMCTSConfig(max_simulations=64), TrainConfig(), SystemConfig(ENGINE="cpu")
+    raise ValueError(f"unknown preset '{name}' (choose tiny, cnn, default, large, huge, reference)")

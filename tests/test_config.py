@@ -73,10 +73,11 @@ def test_env_config():
     assert (e.ROWS, e.COLS, e.NUM_SHAPE_SLOTS, e.ACTION_DIM) == (8, 15, 3, 360)
     with pytest.raises(ValidationError):
         EnvConfig(ROWS=2, COLS=3, PLAYABLE_RANGE_PER_ROW=[(0, 3)])
+    assert EnvConfig(ROWS=20, COLS=20, PLAYABLE_RANGE_PER_ROW=[(0, 20)] * 20).ACTION_DIM == 1200  # wide host engine
     with pytest.raises(ValidationError):
-        EnvConfig(ROWS=20, COLS=20, PLAYABLE_RANGE_PER_ROW=[(0, 20)] * 20)
+        EnvConfig(ROWS=40, COLS=30, PLAYABLE_RANGE_PER_ROW=[(0, 30)] * 40)  # above 1024 cells
     big = EnvConfig.large()
-    assert big.ROWS * big.COLS <= 256
+    assert big.ROWS * big.COLS <= 256  # the largest preset the device engine plays
 
 
 def test_print_config_and_system(capsys):

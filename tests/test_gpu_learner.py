@@ -142,6 +142,51 @@ def test_trainer_step_on_device_batch_changes_params():
     assert torch.isfinite(lg).all() and torch.isfinite(v).all()
 
 
+@pytest.mark.parametrize("kind", ["huge-cnn", "18x18-transformer"])
+@pytest.mark.parametrize("fp32", [True, False])
+def test_learner_trains_on_boards_above_256_cells(kind, fp32):
+    """Boards the device engine and the one-sample-per-workgroup kernels do not hold (more than 256 cells / tokens): the
+    network has no inference engine (leaves go through the module) and the learner's step still runs and fits a fixed
+    batch, on whatever mix of in-tree kernels and library calls its guards pick for that geometry."""
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.presets import build_preset
+    from alphatriangle_amd.rl.core.trainer import TensorBatch, Trainer
+
+    dev = torch.device("cuda")
+    if kind == "huge-cnn":
+        env, mc, _, _, _ = build_preset("huge")
+    else:
+        env = EnvConfig(ROWS=18, COLS=18, PLAYABLE_RANGE_PER_ROW=[(1, 17)] * 18)
+        mc = ModelConfig(TRANSFORMER_LAYERS=1)
+    torch.manual_seed(5)
+    tc = TrainConfig(DEVICE="cuda", BATCH_SIZE=32, BUFFER_CAPACITY=500, MIN_BUFFER_SIZE_TO_TRAIN=64, MAX_TRAINING_STEPS=100,
+                     COMPILE_MODEL=False)
+    SystemConfig(LEARNER_FP32_GEMM="bf16x3" if fp32 else "library").apply_learner_gemm_mode()
+    try:
+        net = NeuralNetwork(mc, env, tc, dev)
+        assert net.engine is None  # no HIP inference engine above 256 cells
+        trainer = Trainer(net, tc, env, autocast_bf16=not fp32)
+        g = torch.Generator(device="cpu").manual_seed(1)
+        n = tc.BATCH_SIZE
+        grid = (torch.randint(0, 3, (n, mc.GRID_INPUT_CHANNELS, env.ROWS, env.COLS), generator=g).float() - 1.0).to(dev)
+        other = torch.rand(n, mc.OTHER_NN_INPUT_FEATURES_DIM, generator=g).to(dev)
+        policy = torch.softmax(torch.randn(n, env.ACTION_DIM, generator=g) * 3.0, dim=1).to(dev)
+        ret = (torch.rand(n, generator=g) * 4.0 - 2.0).to(dev)
+        batch = TensorBatch(grid=grid, other=other, policy_target=policy, returns=ret, weights=torch.ones(n, device=dev),
+                            indices=torch.arange(n, device=dev))
+        losses = []
+        for _ in range(10):
+            info, td = trainer.train_step(batch)
+            assert np.isfinite(info["total_loss"]) and td.shape == (n,)
+            losses.append(info["total_loss"])
+        assert losses[-1] < losses[0], losses
+        net.sync_inference_weights()
+        lg, v = net.evaluate_features(grid, other)
+        assert lg.shape == (n, env.ACTION_DIM) and torch.isfinite(lg).all() and torch.isfinite(v).all()
+    finally:
+        SystemConfig().apply_learner_gemm_mode()
+
+
 @pytest.mark.parametrize("preset", ["cnn", "default"])
 def test_graphed_learner_step_matches_eager_trajectory(preset):
     """COMPILE_MODEL: forward/backward replayed from a HIP graph when the graph passes its guards (no memset nodes,

@@ -14,12 +14,13 @@ import pytest
 from alphatriangle_amd import build_native
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["256-cell-state", "1024-cell-state"])
 @pytest.mark.parametrize("kind", ["address", "thread"])
-def test_host_runtime_is_clean_under_sanitizer(kind):
+def test_host_runtime_is_clean_under_sanitizer(kind, wide):
     if shutil.which("g++") is None:
         pytest.skip("no host C++ compiler")
     try:
-        exe = build_native.build_selftest(kind, verbose=False)
+        exe = build_native.build_selftest(kind, verbose=False, wide=wide)
     except subprocess.CalledProcessError as exc:  # toolchain without the sanitizer runtime
         pytest.skip(f"sanitizer build not available: {exc}")
     env = {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "TSAN_OPTIONS": "halt_on_error=1", "PATH": "/usr/bin:/bin"}

@@ -178,6 +178,27 @@ def test_a_data_parallel_rank_without_a_batch_still_enters_the_all_reduce(tmp_pa
     _spawn(_one_rank_has_no_batch, 2, str(tmp_path))
 
 
+def _shutdown_ends_the_group_threads(rank, world, init, root):
+    """After a run that went through an optimizer step (torch imports torch._dynamo and, with it,
+    torch.distributed.nn.functional on the way), shutdown() has to end the process group's worker threads: a group that
+    stays pinned keeps them alive into interpreter shutdown, where a gloo worker dropping a tensor aborts the process."""
+    code, ctx = _run_rank(rank, world, init, root, lambda r: {}, lambda r: {})
+    assert code == 0
+    before = len(os.listdir("/proc/self/task"))
+    ctx.shutdown()
+    import gc
+
+    gc.collect()
+    after = len(os.listdir("/proc/self/task"))
+    assert after < before, f"rank {rank}: {before} native threads before shutdown, {after} after: the process group is still alive"
+    fn_mod = sys.modules.get("torch.distributed.nn.functional")
+    assert fn_mod is not None and fn_mod.all_reduce.__defaults__[-1] is None  # imported before the group existed
+
+
+def test_shutdown_releases_the_process_group_and_its_threads(tmp_path):
+    _spawn(_shutdown_ends_the_group_threads, 2, str(tmp_path))
+
+
 def _one_rank_leaves(rank, world, init, root):
     if rank == 1:
         # takes part in set-up and three rounds, then disappears without a word

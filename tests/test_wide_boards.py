@@ -1,0 +1,131 @@
+"""Boards above 256 cells: the wide build of the host engine (16 occupancy words per state, up to 1024 cells).
+
+The reference takes any ROWS x COLS (alphatriangle/nn/model.py:123-125 sizes the network from them); here boards of up
+to 256 cells share one 64-byte state between the host and the device engine, larger ones are played by the same C++
+sources compiled with a wider state, on the host only.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from alphatriangle_amd import native
+from alphatriangle_amd.config import AlphaTriangleMCTSConfig, EnvConfig, ModelConfig
+from alphatriangle_amd.env.game_state import GameState
+from alphatriangle_amd.features.extractor import extract_features_batch, extract_state_features
+from alphatriangle_amd.mcts.host_search import run_mcts
+
+
+def _wide_env(rows: int = 18, cols: int = 18) -> EnvConfig:
+    return EnvConfig(ROWS=rows, COLS=cols, PLAYABLE_RANGE_PER_ROW=[(1, cols - 1)] * rows)
+
+
+def _model_for(env: EnvConfig) -> ModelConfig:
+    return ModelConfig(
+        GRID_INPUT_CHANNELS=1, CONV_FILTERS=[8], CONV_KERNEL_SIZES=[3], CONV_STRIDES=[1], CONV_PADDING=[1], NUM_RESIDUAL_BLOCKS=0,
+        RESIDUAL_BLOCK_FILTERS=8, USE_TRANSFORMER=False, FC_DIMS_SHARED=[16], POLICY_HEAD_DIMS=[16], VALUE_HEAD_DIMS=[16],
+        OTHER_NN_INPUT_FEATURES_DIM=8 * env.NUM_SHAPE_SLOTS + 6, NUM_VALUE_ATOMS=11, VALUE_MIN=-5.0, VALUE_MAX=5.0,
+    )
+
+
+def test_both_host_builds_load_side_by_side_and_pick_by_board_size():
+    narrow, wide = native.host(), native.host(600)
+    assert narrow is native.host(256) and wide is native.host(1024) and narrow is not wide
+    assert (narrow.MAX_WORDS, narrow.STATE_BYTES) == (4, 64) and (wide.MAX_WORDS, wide.STATE_BYTES) == (16, 160)
+    with pytest.raises(native.NativeLibraryError):
+        native.host(1025)
+    with pytest.raises(ValueError):
+        EnvConfig(ROWS=33, COLS=32, PLAYABLE_RANGE_PER_ROW=[(0, 32)] * 33)
+    small = GameState(EnvConfig(), 1)
+    big = GameState(_wide_env(), 1)
+    assert native.host_of(small.geometry) is narrow and native.host_of(big.geometry) is wide
+    with pytest.raises(TypeError):  # the two builds share no type: a state of one is not a state of the other
+        wide.extract_features(small.core, 1, 30)
+
+
+def test_the_wide_build_plays_the_same_game_as_the_narrow_one_on_a_board_both_hold():
+    """Same sources, same rules: on a 12x21 board (252 cells) both builds agree move by move."""
+    env = EnvConfig.large()
+    narrow, wide = native.host(), native.host(600)
+    kw = dict(rows=env.ROWS, cols=env.COLS, playable_range=[tuple(r) for r in env.PLAYABLE_RANGE_PER_ROW], slots=env.NUM_SHAPE_SLOTS,
+              min_line_length=env.MIN_LINE_LENGTH, max_shape_tris=env.MAX_SHAPE_TRIANGLES, r_place=env.REWARD_PER_PLACED_TRIANGLE,
+              r_clear=env.REWARD_PER_CLEARED_TRIANGLE, r_alive=env.REWARD_PER_STEP_ALIVE, r_over=env.PENALTY_GAME_OVER,
+              size_weights=list(env.SHAPE_SIZE_WEIGHTS))
+    a, b = narrow.CoreState(narrow.Geometry(**kw), 77), wide.CoreState(wide.Geometry(**kw), 77)
+    rng = np.random.default_rng(5)
+    moves = 0
+    while not a.is_over():
+        va = a.valid_actions()
+        assert va == b.valid_actions() and a.shape_ids() == b.shape_ids()
+        act = int(rng.choice(va))
+        assert a.step(act) == b.step(act)
+        assert np.array_equal(a.occupied(), b.occupied()) and a.game_score() == b.game_score()
+        ga, oa = narrow.extract_features(a, 1, 30)
+        gb, ob = wide.extract_features(b, 1, 30)
+        assert np.array_equal(ga, gb) and np.array_equal(oa, ob)
+        moves += 1
+    assert b.is_over() and moves > 20
+
+
+def test_game_features_and_search_on_a_324_cell_board():
+    env = _wide_env()
+    model = _model_for(env)
+    g = GameState(env, 11)
+    assert g.geometry.cells == 324 and g.geometry.nwords == 6 and len(g.core.pack()) == 160
+    rng = np.random.default_rng(1)
+    cleared = 0
+    for _ in range(60):
+        if g.is_over():
+            break
+        mask = g.valid_mask()
+        va = g.valid_actions()
+        assert mask.sum() == len(va) and mask.shape == (env.ACTION_DIM,)
+        g.step(int(rng.choice(va)))
+        cleared += g.get_last_cleared_triangles()
+    occ = g.get_grid_data_np()["occupied"]
+    assert occ.shape == (18, 18) and occ.sum() > 0 and not occ[:, 0].any() and not occ[:, -1].any()  # death columns stay empty
+    feats = extract_state_features(g, model)
+    assert feats["grid"].shape == (1, 18, 18) and feats["other_features"].shape == (30,)
+    assert np.array_equal(feats["grid"][0] == 1.0, occ) and (feats["grid"][0][:, 0] == -1.0).all()
+    grid, other = extract_features_batch([g, g.copy()], model, 18, 18)
+    assert grid.shape == (2, 1, 18, 18) and np.array_equal(grid[0], feats["grid"]) and np.array_equal(other[1], feats["other_features"])
+
+    class Uniform:
+        calls = 0
+
+        def evaluate_batch_arrays(self, cores):
+            Uniform.calls += 1
+            return np.zeros((len(cores), env.ACTION_DIM), dtype=np.float32), np.zeros(len(cores), dtype=np.float32)
+
+    fresh = GameState(env, 3)
+    mcts = AlphaTriangleMCTSConfig(max_simulations=24, max_depth=4, mcts_batch_size=4, dirichlet_epsilon=0.0)
+    visits, handle = run_mcts(fresh, Uniform(), mcts, seed=9)
+    assert sum(visits.values()) == 24 and all(fresh.valid_mask()[a] for a in visits) and Uniform.calls > 1
+    best = max(visits, key=visits.get)
+    fresh.step(best)
+    visits2, handle2 = run_mcts(fresh, Uniform(), mcts, previous_tree_handle=handle, last_action=best, seed=9)
+    assert handle2 is handle and sum(visits2.values()) >= 24  # the subtree under the chosen move was kept
+
+
+def test_cpu_training_run_on_a_board_above_256_cells(tmp_path):
+    """One command trains on a 18x18 board: wide host engine for self-play, the PyTorch module for the network."""
+    from alphatriangle_amd.config import SystemConfig, TrainConfig
+    from alphatriangle_amd.stats import TrieyeConfig
+    from alphatriangle_amd.stats.serializer import Serializer
+    from alphatriangle_amd.training.runner import run_training
+
+    env = _wide_env()
+    model = _model_for(env)
+    mcts = AlphaTriangleMCTSConfig(max_simulations=6, max_depth=3, mcts_batch_size=6)
+    train = TrainConfig(
+        DEVICE="cpu", WORKER_DEVICE="cpu", NUM_SELF_PLAY_WORKERS=1, BATCH_SIZE=8, BUFFER_CAPACITY=512, MIN_BUFFER_SIZE_TO_TRAIN=16,
+        MAX_TRAINING_STEPS=6, CHECKPOINT_SAVE_FREQ_STEPS=6, LR_SCHEDULER_T_MAX=6, PER_BETA_ANNEAL_STEPS=6, WORKER_UPDATE_FREQ_STEPS=3,
+        N_STEP_RETURNS=2, COMPILE_MODEL=False, AUTO_RESUME_LATEST=False, MAX_EPISODE_MOVES=24, RUN_NAME="wide",
+    )
+    t = TrieyeConfig(app_name="WIDE", run_name="wide")
+    t.persistence.ROOT_DATA_DIR = str(tmp_path)
+    assert run_training("WARNING", train, t, profile=False, model_config_override=model, mcts_config_override=mcts,
+                        env_config_override=env, system_config_override=SystemConfig(ENGINE="auto")) == 0
+    ck = Serializer().load_checkpoint(tmp_path / "WIDE" / "runs" / "wide" / "checkpoints" / "latest.pkl")
+    assert ck.global_step == 6 and ck.episodes_played > 0
