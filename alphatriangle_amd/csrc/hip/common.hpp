@@ -65,6 +65,9 @@ __device__ __forceinline__ float4v mfma_split(const short8& ah, const short8& al
 #define ATRI_SPLIT_F16 1
 #endif
 constexpr bool kSplitF16 = ATRI_SPLIT_F16 != 0;
+#ifndef ATRI_SPLIT_NOMIX
+#define ATRI_SPLIT_NOMIX 0
+#endif
 typedef __attribute__((ext_vector_type(8))) _Float16 half8v;
 typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
 
@@ -91,13 +94,29 @@ __device__ __forceinline__ float4v split_mma(const short8& a, const short8& b, f
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
   }
 }
+// v - value(h): what the lo operand has to carry.  For fp16 pairs this is written as fma(h, -1, v) - the same single
+// rounding as the subtraction - which the compiler selects as one v_fma_mix_f32 (the conversion of h rides in the
+// instruction) instead of v_cvt_f32_f16 + v_sub_f32: one vector instruction less per split element.
+__device__ __forceinline__ float split_residual(float v, unsigned short h) {
+  if constexpr (kSplitF16) {
+#if ATRI_SPLIT_NOMIX
+    return v - split_unpack(h);
+#else
+    float minus_one = -1.0f;
+    asm("" : "+s"(minus_one));  // opaque: a literal -1 is folded back into a subtraction of the converted value
+    return __builtin_fmaf((float)__builtin_bit_cast(_Float16, h), minus_one, v);
+#endif
+  } else {
+    return v - split_unpack(h);
+  }
+}
 // fp32 -> (hi, lo) pair of split operands with hi + lo ~= x.
 __device__ __forceinline__ void split_op8(const float (&v)[8], short8& hi, short8& lo) {
   const uint4v uh = {split_pack2(v[0], v[1]), split_pack2(v[2], v[3]), split_pack2(v[4], v[5]), split_pack2(v[6], v[7])};
   hi = __builtin_bit_cast(short8, uh);
   float r[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = v[j] - split_unpack((unsigned short)hi[j]);
+  for (int j = 0; j < 8; ++j) r[j] = split_residual(v[j], (unsigned short)hi[j]);
   const uint4v ul = {split_pack2(r[0], r[1]), split_pack2(r[2], r[3]), split_pack2(r[4], r[5]), split_pack2(r[6], r[7])};
   lo = __builtin_bit_cast(short8, ul);
 }

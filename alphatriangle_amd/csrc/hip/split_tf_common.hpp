@@ -145,8 +145,8 @@ __device__ __forceinline__ void ln_finish(LnRows& x, unsigned char* dst, float e
       const float4& q = x.v[pass][j];
       const float o0 = q.x * rstd, o1 = q.y * rstd, o2 = q.z * rstd, o3 = q.w * rstd;
       const unsigned h0 = split_pack2(o0, o1), h1 = split_pack2(o2, o3);
-      const float r0 = o0 - split_unpack((unsigned short)(h0 & 0xFFFF)), r1 = o1 - split_unpack((unsigned short)(h0 >> 16));
-      const float r2 = o2 - split_unpack((unsigned short)(h1 & 0xFFFF)), r3 = o3 - split_unpack((unsigned short)(h1 >> 16));
+      const float r0 = split_residual(o0, (unsigned short)(h0 & 0xFFFF)), r1 = split_residual(o1, (unsigned short)(h0 >> 16));
+      const float r2 = split_residual(o2, (unsigned short)(h1 & 0xFFFF)), r3 = split_residual(o3, (unsigned short)(h1 >> 16));
       unsigned char* p = dst + row * kStrideS + (j * 8 + l8) * 8;
       *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(p + kPlane) = make_uint2(split_pack2(r0, r1), split_pack2(r2, r3));

@@ -66,12 +66,14 @@ constexpr int kEncLds = 2 * kRegion + kBiasFloats * 4;  // 152,064
 // Scores of query tile t of this wave against all 128 keys of its head, key-major: st[kt][j] = score of key
 // 16 kt + 4 q4 + j for query l15 of the tile, in log2 units.  Padded keys get -1e30 (probability 0): branch-free, and
 // with TAIL (more than 112 tokens) only the last key tile can hold padding.
+// The accumulators start at `init`: a constant added to every score costs nothing there.
 template <bool TAIL>
-__device__ __forceinline__ void attn_scores(float4v (&st)[8], const short8* kimg, const short8& qh, const short8& ql, int HW, int q4) {
+__device__ __forceinline__ void attn_scores(float4v (&st)[8], const short8* kimg, const short8& qh, const short8& ql, int HW, int q4,
+                                            float init) {
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt) {
     const short8 kh = kimg[(size_t)kt * 128], kl = kimg[(size_t)kt * 128 + 64];
-    st[kt] = mma_split3(kh, kl, qh, ql, (float4v){0.f, 0.f, 0.f, 0.f});
+    st[kt] = mma_split3(kh, kl, qh, ql, (float4v){init, init, init, init});
   }
 #pragma unroll
   for (int kt = TAIL ? 7 : 0; kt < 8; ++kt)
@@ -94,7 +96,7 @@ __device__ __forceinline__ bool attention_tiles(const short8 (&qh)[4], const sho
   float4v s[8];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    attn_scores<TAIL>(s, kimg, qh[t], ql[t], HW, q4);
+    attn_scores<TAIL>(s, kimg, qh[t], ql[t], HW, q4, SAFE ? 0.f : kFreeShift);  // the free pass's shift rides in the accumulators
     if (!SAFE && t == 3) {  // the weights of the GEMM after attention fly during the last tile (the ring is idle until then)
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) load_wslice(w, kc, after);
@@ -106,14 +108,14 @@ __device__ __forceinline__ bool attention_tiles(const short8 (&qh)[4], const sho
       for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) m = fmaxf(m, s[kt][j]);
-      m = quad_row_max(m);
+      m = quad_row_max(m) - kSafeShift;
     }
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        s[kt][j] = __builtin_amdgcn_exp2f(SAFE ? s[kt][j] - m + kSafeShift : s[kt][j] + kFreeShift);
+        s[kt][j] = __builtin_amdgcn_exp2f(SAFE ? s[kt][j] - m : s[kt][j]);
         sum += s[kt][j];
       }
     sum = quad_row_sum(sum);
@@ -126,7 +128,7 @@ __device__ __forceinline__ bool attention_tiles(const short8 (&qh)[4], const sho
       o0 = mma_split3(vth[kb][0], vtl[kb][0], ph, pl, o0);
       o1 = mma_split3(vth[kb][1], vtl[kb][1], ph, pl, o1);
     }
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);  // 1 ulp: the division's scale / fixup sequence is ten more vector instructions per tile
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       o0[j] *= inv;

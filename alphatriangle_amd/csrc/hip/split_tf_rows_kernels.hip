@@ -117,7 +117,8 @@ __device__ __forceinline__ bool qa_tiles(const short8* kimg, const short8* vimg,
 #pragma unroll
     for (int kt = 0; kt < 16; ++kt) {
       const short8 kh = kimg[(kt * 2) * 64], kl = kimg[(kt * 2 + 1) * 64];
-      st[kt] = mma_split3(kh, kl, Qh[t], Ql[t], (float4v){0.f, 0.f, 0.f, 0.f});
+      const float init = SAFE ? 0.f : kFreeShift;  // the free pass's shift rides in the accumulators
+      st[kt] = mma_split3(kh, kl, Qh[t], Ql[t], (float4v){init, init, init, init});
       if (kt >= kt_full) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -128,13 +129,13 @@ __device__ __forceinline__ bool qa_tiles(const short8* kimg, const short8* vimg,
         for (int j = 0; j < 4; ++j) m = fmaxf(m, st[kt][j]);
       }
     }
-    if (SAFE) m = quad_row_max(m);
+    if (SAFE) m = quad_row_max(m) - kSafeShift;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 16; ++kt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        st[kt][j] = __builtin_amdgcn_exp2f(SAFE ? st[kt][j] - m + kSafeShift : st[kt][j] + kFreeShift);  // log2 units
+        st[kt][j] = __builtin_amdgcn_exp2f(SAFE ? st[kt][j] - m : st[kt][j]);  // log2 units
         sum += st[kt][j];
       }
     sum = quad_row_sum(sum);
@@ -149,7 +150,7 @@ __device__ __forceinline__ bool qa_tiles(const short8* kimg, const short8* vimg,
       o0 = mma_split3(vb[0], vb[64], ph, pl, o0);
       o1 = mma_split3(vb[128], vb[192], ph, pl, o1);
     }
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);  // 1 ulp, one instruction instead of the division's ten
     // lane holds dims q4 * 8 .. + 7 of query q0 + l15
     if (q0 + l15 < HW) {
       float* op = og + (size_t)(q0 + l15) * kDs;
