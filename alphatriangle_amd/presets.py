@@ -70,5 +70,6 @@ def build_preset(name: str) -> tuple[EnvConfig, ModelConfig, AlphaTriangleMCTSCo
         rows, cols = 20, 30
         ranges = [(max(0, 4 - r, r - (rows - 5)), cols - max(0, 4 - r, r - (rows - 5))) for r in range(rows)]
         env = EnvConfig(ROWS=rows, COLS=cols, PLAYABLE_RANGE_PER_ROW=ranges, NUM_SHAPE_SLOTS=3)
-        return env, ModelConfig.cnn_only(), AlphaTriangleMCTSConfig(max_simulations=64), TrainConfig(), SystemConfig(ENGINE="cpu")
+        train = TrainConfig(BATCH_SIZE=128, BUFFER_CAPACITY=200_000, MIN_BUFFER_SIZE_TO_TRAIN=2_000, NUM_SELF_PLAY_WORKERS=8)
+        return env, ModelConfig.cnn_only(), AlphaTriangleMCTSConfig(max_simulations=64), train, SystemConfig(ENGINE="cpu")
     raise ValueError(f"unknown preset '{name}' (choose tiny, cnn, default, large, huge, reference)")
