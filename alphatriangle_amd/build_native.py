@@ -97,6 +97,14 @@ def build_host(force: bool = False, verbose: bool = True) -> Path:
     return HOST_SO
 
 
+def hip_objects() -> list[tuple[Path, str, list[str]]]:
+    """(source, object stem, extra defines) of every object of the kernel library: one per ``.hip`` file, plus the device
+    engine a second time with the wide host engine's 16-word game state (boards of 257 - 1024 cells, ``atriw_*`` entries)."""
+    objs: list[tuple[Path, str, list[str]]] = [(s, s.stem, []) for s in hip_sources()]
+    objs.append((CSRC / "hip" / "engine_kernels.hip", "engine_kernels_wide", [f"-DATRI_MAX_WORDS={WIDE_WORDS}"]))
+    return objs
+
+
 def build_hip(force: bool = False, verbose: bool = True) -> Path:
     srcs = hip_sources()
     if not srcs:
@@ -109,18 +117,18 @@ def build_hip(force: bool = False, verbose: bool = True) -> Path:
     obj_dir = PKG_DIR / "build" / "hip"
     obj_dir.mkdir(parents=True, exist_ok=True)
     procs = []
-    for s in srcs:
-        o = obj_dir / (s.stem + ".o")
+    for s, stem, defines in hip_objects():
+        o = obj_dir / (stem + ".o")
         objs.append(o)
         if not force and _newer(o, [s] + _all_headers() + [Path(__file__)]):
             continue
-        cmd = [hipcc, *[f for f in HIP_FLAGS if f != "-shared"], "-c", str(s), "-o", str(o)]
+        cmd = [hipcc, *[f for f in HIP_FLAGS if f != "-shared"], *defines, "-c", str(s), "-o", str(o)]
         if verbose:
             print("[build_native] hip:", " ".join(cmd), flush=True)
-        procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
+        procs.append((stem, subprocess.Popen(cmd)))
+    for stem, p in procs:
         if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {s}")
+            raise RuntimeError(f"hipcc failed on {stem}")
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(o) for o in objs], "-o", str(HIP_SO)]
     if verbose:
         print("[build_native] link:", " ".join(link), flush=True)

@@ -74,7 +74,7 @@ def train(
     simulations: Annotated[int | None, typer.Option(help="MCTS simulations per move.")] = None,
     max_steps: Annotated[int | None, typer.Option(help="Override MAX_TRAINING_STEPS.")] = None,
     workers: Annotated[int | None, typer.Option(help="CPU self-play workers (cpu engine).")] = None,
-    preset: Annotated[str, typer.Option(help="Config preset: default, cnn, tiny, large, huge (20x30 board, host engine), reference.")] = "default",
+    preset: Annotated[str, typer.Option(help="Config preset: default, cnn, tiny, large, huge (20x30 board), reference.")] = "default",
     data_root: Annotated[str | None, typer.Option(help="Root directory for run data (default .trieye_data).")] = None,
     layout: Annotated[str, typer.Option(help="Multi-GPU role layout: colocated (every rank plays and learns) or split (actor ranks + learner ranks).")] = "colocated",
     learners: Annotated[int, typer.Option(help="Learner ranks of the split layout (the rest self-play).")] = 1,

@@ -27,6 +27,22 @@ using namespace atri;
 
 #pragma clang fp contract(off)
 
+// The file is compiled twice into the kernel library: with the 64-byte game state (boards up to 256 cells; C entry points
+// atri_*) and, with -DATRI_MAX_WORDS=16, with the 160-byte state of the wide host engine (boards up to 1024 cells; entry
+// points atriw_*).  Kernels and structures of the two builds live in different namespaces.
+#if ATRI_MAX_WORDS != 4
+#define ATRI_ENG_NS atri_engine_wide
+#define ATRI_ENG(name) atriw_##name
+// a 160-byte state per lane: the one-wave workgroups get the whole register file instead of the default 128 registers
+#define ATRI_ENG_BOUNDS __launch_bounds__(64)
+#else
+#define ATRI_ENG_NS atri_engine
+#define ATRI_ENG(name) atri_##name
+#define ATRI_ENG_BOUNDS
+#endif
+
+namespace ATRI_ENG_NS {
+
 struct TreeBufs {
   State* states[2];    // [G][C]
   NodeMeta* meta[2];   // [G][C]
@@ -430,7 +446,7 @@ __global__ void init_roots_kernel(GeomView g, TreeBufs tb, SearchParams sp, uint
 
 // One simulation wave for one tree: (1) consume the network outputs of the previous wave
 // (edge initialisation + backup), (2) select up to L new leaves and expand them.
-__global__ void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int do_consume, int do_select) {
+__global__ ATRI_ENG_BOUNDS void tree_wave_kernel(GeomView g, TreeBufs tb, SearchParams sp, int do_consume, int do_select) {
   const int t = blockIdx.x, lane = threadIdx.x;
   State* states = tree_states(tb, t);
   NodeMeta* meta = tree_meta(tb, t);
@@ -711,7 +727,7 @@ __device__ void emit_experience(const GeomView& g, const TreeBufs& tb, GameBufs&
   if (lane == 0) gb.rp_ret[dst] = ret;
 }
 
-__global__ void commit_moves_kernel(GeomView g, TreeBufs tb, GameBufs gb) {
+__global__ ATRI_ENG_BOUNDS void commit_moves_kernel(GeomView g, TreeBufs tb, GameBufs gb) {
   const int t = blockIdx.x, lane = threadIdx.x;
   const State* states = tree_states(tb, t);
   const NodeMeta* meta = tree_meta(tb, t);
@@ -1002,44 +1018,47 @@ __global__ void reroot_kernel(GeomView g, TreeBufs tb, GameBufs gb) {
   }
 }
 
+}  // namespace ATRI_ENG_NS
+using namespace ATRI_ENG_NS;
+
 // ------------------------------------------------------------------ C ABI
 extern "C" {
 
-int atri_reset_states(const GeomView* g, void* states, const void* seeds, int n, hipStream_t s) {
+int ATRI_ENG(reset_states)(const GeomView* g, void* states, const void* seeds, int n, hipStream_t s) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(reset_states_kernel, dim3(n), dim3(64), 0, s, *g, (State*)states, (const uint64_t*)seeds, n);
   return (int)hipGetLastError();
 }
-int atri_step_states(const GeomView* g, void* states, const int32_t* actions, float* rewards, int32_t* done, int n,
+int ATRI_ENG(step_states)(const GeomView* g, void* states, const int32_t* actions, float* rewards, int32_t* done, int n,
                      hipStream_t s) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(step_states_kernel, dim3(n), dim3(64), 0, s, *g, (State*)states, actions, rewards, done, n);
   return (int)hipGetLastError();
 }
-int atri_valid_mask(const GeomView* g, const void* states, uint8_t* mask, int n, hipStream_t s) {
+int ATRI_ENG(valid_mask)(const GeomView* g, const void* states, uint8_t* mask, int n, hipStream_t s) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(valid_mask_kernel, dim3(n), dim3(64), 0, s, *g, (const State*)states, mask, n);
   return (int)hipGetLastError();
 }
-int atri_features(const GeomView* g, const void* states, float* grid, float* other, int other_dim, int n,
+int ATRI_ENG(features)(const GeomView* g, const void* states, float* grid, float* other, int other_dim, int n,
                   hipStream_t s) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(features_kernel, dim3(n), dim3(64), 0, s, *g, (const State*)states, grid, other, other_dim, n);
   return (int)hipGetLastError();
 }
-int atri_tree_reset(const TreeBufs* tb, const void* roots, const uint8_t* mask, hipStream_t s) {
+int ATRI_ENG(tree_reset)(const TreeBufs* tb, const void* roots, const uint8_t* mask, hipStream_t s) {
   hipLaunchKernelGGL(tree_reset_kernel, dim3(tb->G), dim3(64), 0, s, *tb, (const State*)roots, mask);
   return (int)hipGetLastError();
 }
-int atri_prepare_roots(const GeomView* g, const TreeBufs* tb, hipStream_t s) {
+int ATRI_ENG(prepare_roots)(const GeomView* g, const TreeBufs* tb, hipStream_t s) {
   hipLaunchKernelGGL(prepare_roots_kernel, dim3(tb->G), dim3(64), 0, s, *g, *tb);
   return (int)hipGetLastError();
 }
-int atri_init_roots(const GeomView* g, const TreeBufs* tb, const SearchParams* sp, void* noise_rng, hipStream_t s) {
+int ATRI_ENG(init_roots)(const GeomView* g, const TreeBufs* tb, const SearchParams* sp, void* noise_rng, hipStream_t s) {
   hipLaunchKernelGGL(init_roots_kernel, dim3(tb->G), dim3(64), 0, s, *g, *tb, *sp, (uint64_t*)noise_rng);
   return (int)hipGetLastError();
 }
-int atri_tree_wave(const GeomView* g, const TreeBufs* tb, const SearchParams* sp, int do_consume, int do_select,
+int ATRI_ENG(tree_wave)(const GeomView* g, const TreeBufs* tb, const SearchParams* sp, int do_consume, int do_select,
                    hipStream_t s) {
   if (sp->max_depth > tb->P) return -10;
   hipLaunchKernelGGL(tree_wave_kernel, dim3(tb->G), dim3(64), 0, s, *g, *tb, *sp, do_consume, do_select);
@@ -1049,21 +1068,21 @@ int atri_tree_wave(const GeomView* g, const TreeBufs* tb, const SearchParams* sp
   }
   return (int)hipGetLastError();
 }
-int atri_root_visits(const TreeBufs* tb, int32_t* visits, hipStream_t s) {
+int ATRI_ENG(root_visits)(const TreeBufs* tb, int32_t* visits, hipStream_t s) {
   hipLaunchKernelGGL(root_visits_kernel, dim3(tb->G), dim3(64), 0, s, *tb, visits);
   return (int)hipGetLastError();
 }
-int atri_commit_moves(const GeomView* g, const TreeBufs* tb, const GameBufs* gb, hipStream_t s) {
+int ATRI_ENG(commit_moves)(const GeomView* g, const TreeBufs* tb, const GameBufs* gb, hipStream_t s) {
   hipLaunchKernelGGL(commit_moves_kernel, dim3(tb->G), dim3(64), 0, s, *g, *tb, *gb);
   return (int)hipGetLastError();
 }
-int atri_reroot(const GeomView* g, const TreeBufs* tb, const GameBufs* gb, hipStream_t s) {
+int ATRI_ENG(reroot)(const GeomView* g, const TreeBufs* tb, const GameBufs* gb, hipStream_t s) {
   hipLaunchKernelGGL(reroot_kernel, dim3(tb->G), dim3(64), 0, s, *g, *tb, *gb);
   return (int)hipGetLastError();
 }
-int atri_sizeof_treebufs() { return (int)sizeof(TreeBufs); }
-int atri_sizeof_gamebufs() { return (int)sizeof(GameBufs); }
-int atri_sizeof_geomview() { return (int)sizeof(GeomView); }
-int atri_sizeof_searchparams() { return (int)sizeof(SearchParams); }
+int ATRI_ENG(sizeof_treebufs)() { return (int)sizeof(TreeBufs); }
+int ATRI_ENG(sizeof_gamebufs)() { return (int)sizeof(GameBufs); }
+int ATRI_ENG(sizeof_geomview)() { return (int)sizeof(GeomView); }
+int ATRI_ENG(sizeof_searchparams)() { return (int)sizeof(SearchParams); }
 
 }  // extern "C"

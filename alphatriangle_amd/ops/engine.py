@@ -1,8 +1,8 @@
 """HBM-resident batched game + tree engine (Python face of csrc/hip/engine_kernels.hip).
 
 ``GpuTreeEngine`` owns, for ``G`` concurrent games on one GPU:
-  * two node arenas (states 64 B, node meta 32 B, dense 16 B edges) so re-rooting can
-    compact the reused subtree from one arena into the other,
+  * two node arenas (states 64 B - 160 B on boards above 256 cells -, node meta 32 B, dense 16 B edges) so re-rooting
+    can compact the reused subtree from one arena into the other,
   * the per-wave leaf slots (selection paths, network input rows),
   * the per-game self-play state (n-step pending ring, episode counters).
 
@@ -28,7 +28,8 @@ from . import hipbind as hb
 
 logger = logging.getLogger(__name__)
 
-STATE_BYTES = 64
+STATE_BYTES = 64        # boards up to 256 cells (four occupancy words)
+WIDE_STATE_BYTES = 160  # boards of 257 - 1024 cells (sixteen words): the wide build of the host and the device engine
 META_BYTES = 32
 EDGE_BYTES = 16
 SLOT_NONE, SLOT_EXPAND, SLOT_TERMINAL, SLOT_DEPTHCAP = 0, 1, 2, 3
@@ -56,6 +57,10 @@ class GpuTreeEngine:
         self.device = torch.device(device)
         self.geom_host = get_geometry(env_config)
         self.geom = hb.DeviceGeometry(self.geom_host, self.device)
+        # the kernel file is built twice: entry points atri_* for the 64-byte state, atriw_* for the 160-byte one
+        self.wide = int(self.geom_host.nwords) > 4
+        self.state_bytes = WIDE_STATE_BYTES if self.wide else STATE_BYTES
+        self._api = "atriw_" if self.wide else "atri_"
         self.G = int(games)
         self.L = int(leaves_per_tree)
         self.A = int(self.geom_host.action_dim)
@@ -71,7 +76,7 @@ class GpuTreeEngine:
         G, Cn, A, L = self.G, self.C, self.A, self.L
         edge_bytes = 2 * G * Cn * A * EDGE_BYTES
         logger.info("GpuTreeEngine: %d games x %d nodes x %d actions -> %.2f GiB of edges in HBM", G, Cn, A, edge_bytes / 2**30)
-        self.states = torch.zeros(2, G, Cn, STATE_BYTES, dtype=torch.uint8, device=dev)
+        self.states = torch.zeros(2, G, Cn, self.state_bytes, dtype=torch.uint8, device=dev)
         self.meta = torch.zeros(2, G, Cn, META_BYTES, dtype=torch.uint8, device=dev)
         self.edges = torch.empty(2, G, Cn, A, 4, dtype=torch.int32, device=dev)
         self.cur = torch.zeros(G, dtype=torch.int32, device=dev)
@@ -87,7 +92,7 @@ class GpuTreeEngine:
         self.noise_rng = torch.from_numpy(
             np.random.default_rng(seed ^ 0x5EED).integers(1, 2**62, size=G, dtype=np.int64)
         ).to(dev)
-        self.root_states = torch.zeros(G, STATE_BYTES, dtype=torch.uint8, device=dev)
+        self.root_states = torch.zeros(G, self.state_bytes, dtype=torch.uint8, device=dev)
         self.census = torch.zeros(G, CENSUS_WIDTH, dtype=torch.int32, device=dev)
         # batch compaction: a selecting wave writes the rows of the leaves that need an evaluation densely and counts them
         self.compact = bool(compact)
@@ -142,27 +147,27 @@ class GpuTreeEngine:
         s = s.to(self.device)
         if s.numel() != self.G:
             raise ValueError("need one seed per game")
-        hb.call("atri_reset_states", self.geom.ref(), hb.ptr(self.root_states), hb.ptr(s), hb.i32(self.G))
+        hb.call(self._api + "reset_states", self.geom.ref(), hb.ptr(self.root_states), hb.ptr(s), hb.i32(self.G))
         self.set_roots(self.root_states)
 
     def set_roots(self, packed_states: torch.Tensor) -> None:
-        """Start fresh trees from packed 64-byte root states ``[G, 64]`` uint8."""
+        """Start fresh trees from packed root states ``[G, state_bytes]`` uint8 (``GameState.core.pack()`` of the same board)."""
         st = packed_states.to(self.device).contiguous()
-        if st.shape != (self.G, STATE_BYTES):
-            raise ValueError("packed_states must be [G, 64] uint8")
+        if st.shape != (self.G, self.state_bytes) or st.dtype != torch.uint8:
+            raise ValueError(f"packed_states must be [G, {self.state_bytes}] uint8")
         self.cur.zero_()
-        hb.call("atri_tree_reset", C.byref(self.tb), hb.ptr(st), hb.ptr(None))
+        hb.call(self._api + "tree_reset", C.byref(self.tb), hb.ptr(st), hb.ptr(None))
 
     def prepare_roots(self) -> None:
-        hb.call("atri_prepare_roots", self.geom.ref(), C.byref(self.tb))
+        hb.call(self._api + "prepare_roots", self.geom.ref(), C.byref(self.tb))
 
     def init_roots(self) -> None:
-        hb.call("atri_init_roots", self.geom.ref(), C.byref(self.tb), C.byref(self.sp), hb.ptr(self.noise_rng))
+        hb.call(self._api + "init_roots", self.geom.ref(), C.byref(self.tb), C.byref(self.sp), hb.ptr(self.noise_rng))
 
     def wave(self, consume: bool, select: bool) -> None:
         """One simulation wave.  With compaction, a selecting wave is followed by the slot scan and the feature kernel
         (same launch call); ``self.live`` then holds the number of dense feature rows = leaves that need an evaluation."""
-        hb.call("atri_tree_wave", self.geom.ref(), C.byref(self.tb), C.byref(self.sp), hb.i32(1 if consume else 0), hb.i32(1 if select else 0))
+        hb.call(self._api + "tree_wave", self.geom.ref(), C.byref(self.tb), C.byref(self.sp), hb.i32(1 if consume else 0), hb.i32(1 if select else 0))
 
     def census_totals(self) -> torch.Tensor:
         """Per-kind leaf-slot counts and the non-finite evaluation count summed over all trees (``[CENSUS_WIDTH]`` int64)."""
@@ -170,33 +175,40 @@ class GpuTreeEngine:
 
     def root_visits(self) -> torch.Tensor:
         out = torch.zeros(self.G, self.A, dtype=torch.int32, device=self.device)
-        hb.call("atri_root_visits", C.byref(self.tb), hb.ptr(out))
+        hb.call(self._api + "root_visits", C.byref(self.tb), hb.ptr(out))
         return out
 
     def current_root_states(self) -> torch.Tensor:
-        """Packed root states ``[G, 64]`` of the active arenas."""
+        """Packed root states ``[G, state_bytes]`` of the active arenas."""
         idx = self.cur.long()
         return self.states[idx, torch.arange(self.G, device=self.device), 0]
 
     # ------------------------------------------------------------------ batched engine ops on packed states
+    def _check_states(self, states: torch.Tensor) -> None:
+        if states.dim() != 2 or states.shape[1] != self.state_bytes or states.dtype != torch.uint8 or not states.is_contiguous():
+            raise ValueError(f"states must be a contiguous [n, {self.state_bytes}] uint8 tensor")
+
     def step_states(self, states: torch.Tensor, actions: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        self._check_states(states)
         n = states.shape[0]
         rewards = torch.zeros(n, dtype=torch.float32, device=self.device)
         done = torch.zeros(n, dtype=torch.int32, device=self.device)
-        hb.call("atri_step_states", self.geom.ref(), hb.ptr(states), hb.ptr(actions.to(torch.int32)), hb.ptr(rewards), hb.ptr(done), hb.i32(n))
+        hb.call(self._api + "step_states", self.geom.ref(), hb.ptr(states), hb.ptr(actions.to(torch.int32)), hb.ptr(rewards), hb.ptr(done), hb.i32(n))
         return rewards, done
 
     def valid_mask(self, states: torch.Tensor) -> torch.Tensor:
+        self._check_states(states)
         n = states.shape[0]
         mask = torch.zeros(n, self.A, dtype=torch.uint8, device=self.device)
-        hb.call("atri_valid_mask", self.geom.ref(), hb.ptr(states), hb.ptr(mask), hb.i32(n))
+        hb.call(self._api + "valid_mask", self.geom.ref(), hb.ptr(states), hb.ptr(mask), hb.i32(n))
         return mask
 
     def features(self, states: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        self._check_states(states)
         n = states.shape[0]
         grid = torch.zeros(n, self.cells, dtype=torch.float32, device=self.device)
         other = torch.zeros(n, self.other_dim, dtype=torch.float32, device=self.device)
-        hb.call("atri_features", self.geom.ref(), hb.ptr(states), hb.ptr(grid), hb.ptr(other), hb.i32(self.other_dim), hb.i32(n))
+        hb.call(self._api + "features", self.geom.ref(), hb.ptr(states), hb.ptr(grid), hb.ptr(other), hb.i32(self.other_dim), hb.i32(n))
         return grid, other
 
     # ------------------------------------------------------------------ self-play state
@@ -224,7 +236,7 @@ class GpuTreeEngine:
         self.ep_cleared = torch.zeros(self.ep_ring, dtype=torch.int32, device=dev)
         self.ep_count = torch.zeros(1, dtype=torch.int64, device=dev)
         self.move_stats = torch.zeros(8, dtype=torch.float32, device=dev)
-        self.next_root = torch.zeros(G, STATE_BYTES, dtype=torch.uint8, device=dev)
+        self.next_root = torch.zeros(G, self.state_bytes, dtype=torch.uint8, device=dev)
         self.reroot_child = torch.zeros(G, dtype=torch.int32, device=dev)
         self.chosen_action = torch.zeros(G, dtype=torch.int32, device=dev)
         self.gamma_pow = torch.tensor([gamma**i for i in range(R + 1)], dtype=torch.float32, device=dev)
@@ -278,9 +290,9 @@ class GpuTreeEngine:
     def commit_moves(self) -> None:
         if self.gb is None:
             raise RuntimeError("attach_replay must be called before commit_moves")
-        hb.call("atri_commit_moves", self.geom.ref(), C.byref(self.tb), C.byref(self.gb))
+        hb.call(self._api + "commit_moves", self.geom.ref(), C.byref(self.tb), C.byref(self.gb))
 
     def reroot(self) -> None:
         if self.gb is None:
             raise RuntimeError("attach_replay must be called before reroot")
-        hb.call("atri_reroot", self.geom.ref(), C.byref(self.tb), C.byref(self.gb))
+        hb.call(self._api + "reroot", self.geom.ref(), C.byref(self.tb), C.byref(self.gb))

@@ -154,6 +154,10 @@ def lib() -> C.CDLL:
             ("atri_sizeof_searchparams", SearchParamsC),
             ("atri_sizeof_treebufs", TreeBufsC),
             ("atri_sizeof_gamebufs", GameBufsC),
+            ("atriw_sizeof_geomview", GeomViewC),
+            ("atriw_sizeof_searchparams", SearchParamsC),
+            ("atriw_sizeof_treebufs", TreeBufsC),
+            ("atriw_sizeof_gamebufs", GameBufsC),
         ):
             f = getattr(handle, fn)
             f.restype = C.c_int
@@ -199,9 +203,6 @@ class DeviceGeometry:
     """Geometry tables mirrored into HBM plus the by-value ``GeomView`` kernel argument."""
 
     def __init__(self, geom: Any, device: torch.device):
-        if geom.nwords > 4:
-            # the device engine's tree holds 64-byte states (four occupancy words); the wide host engine plays larger boards
-            raise ValueError(f"the HIP game / tree engine holds boards of up to 256 cells, this one has {geom.cells}")
         self.geom = geom
         self.device = device
 

@@ -5,8 +5,9 @@
 * ``default`` - default grid, CNN + Transformer encoder, 400 simulations on GPU engines
   (the reference's own default of 64 simulations is kept for the cpu engine by ``reference``).
 * ``large``   - 12x21 grid, 8-layer Transformer, 800 simulations, HBM-sized replay.
-* ``huge``    - 20x30 grid (600 cells, above the 256 the device engine's 64-byte state holds): CNN network, 64
-  simulations, host workers on the wide build of the C++ engine, learner on the training device.
+* ``huge``    - 20x30 grid (600 cells: the wide build of the host and the device engine, 160-byte game states): CNN
+  network, 64 simulations, 1024 games per GPU with leaves evaluated by the PyTorch module (no HIP inference engine tiles
+  that board); host workers on a machine without a GPU.
 * ``reference`` - every reference default untouched (64 simulations, 8 CPU workers).
 """
 
@@ -71,5 +72,5 @@ def build_preset(name: str) -> tuple[EnvConfig, ModelConfig, AlphaTriangleMCTSCo
         ranges = [(max(0, 4 - r, r - (rows - 5)), cols - max(0, 4 - r, r - (rows - 5))) for r in range(rows)]
         env = EnvConfig(ROWS=rows, COLS=cols, PLAYABLE_RANGE_PER_ROW=ranges, NUM_SHAPE_SLOTS=3)
         train = TrainConfig(BATCH_SIZE=128, BUFFER_CAPACITY=200_000, MIN_BUFFER_SIZE_TO_TRAIN=2_000, NUM_SELF_PLAY_WORKERS=8)
-        return env, ModelConfig.cnn_only(), AlphaTriangleMCTSConfig(max_simulations=64), train, SystemConfig(ENGINE="cpu")
+        return env, ModelConfig.cnn_only(), AlphaTriangleMCTSConfig(max_simulations=64), train, SystemConfig(GAMES_PER_GPU=1024)
     raise ValueError(f"unknown preset '{name}' (choose tiny, cnn, default, large, huge, reference)")

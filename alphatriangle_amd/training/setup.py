@@ -86,14 +86,6 @@ def setup_training_components(
         neural_net = NeuralNetwork(model_config, env_config, train_config, device, inference_dtype=system_config.INFERENCE_DTYPE)
 
         use_gpu_engine = system_config.ENGINE == "gpu" or (system_config.ENGINE == "auto" and device.type == "cuda")
-        if env_config.ROWS * env_config.COLS > 256:
-            # the HBM-resident tree keeps 64-byte states (256 cells); larger boards are played by the wide host engine
-            if system_config.ENGINE == "gpu":
-                raise RuntimeError("SystemConfig.ENGINE='gpu' holds boards of up to 256 cells; use ENGINE='cpu' (or 'auto') for this one")
-            if use_gpu_engine:
-                logger.warning("Board of %d cells: self-play runs on the host engine (the GPU tree holds up to 256 cells).",
-                               env_config.ROWS * env_config.COLS)
-            use_gpu_engine = False
         if use_gpu_engine and neural_net.engine is None:
             # a model the HIP kernels do not tile (see ops/inference.py: engine_supports): the GPU tree still runs,
             # its leaves are evaluated by the PyTorch module

@@ -28,12 +28,19 @@ def _packed(states):
     return torch.from_numpy(np.stack([np.frombuffer(s.core.pack(), dtype=np.uint8) for s in states]).copy())
 
 
-@pytest.mark.parametrize("env", [EnvConfig(), EnvConfig(ROWS=5, COLS=6, PLAYABLE_RANGE_PER_ROW=[(0, 6)] * 5, NUM_SHAPE_SLOTS=2), EnvConfig.large()])
+_WIDE_ENV = EnvConfig(ROWS=18, COLS=18, PLAYABLE_RANGE_PER_ROW=[(1, 17)] * 18)   # 324 cells: six occupancy words
+_HUGE_ENV = EnvConfig(ROWS=20, COLS=30, PLAYABLE_RANGE_PER_ROW=[(max(0, 4 - r, r - 15), 30 - max(0, 4 - r, r - 15)) for r in range(20)])
+
+
+@pytest.mark.parametrize("env", [EnvConfig(), EnvConfig(ROWS=5, COLS=6, PLAYABLE_RANGE_PER_ROW=[(0, 6)] * 5, NUM_SHAPE_SLOTS=2), EnvConfig.large(),
+                                 _WIDE_ENV, _HUGE_ENV], ids=["8x15", "5x6", "12x21", "18x18-wide", "20x30-wide"])
 def test_step_valid_features_bit_exact(env):
+    """Boards above 256 cells run the wide build of both engines (160-byte states, ``atriw_*`` entry points)."""
     rng = random.Random(5)
     other_dim = 8 * env.NUM_SHAPE_SLOTS + 6
     eng = _engine(env, AlphaTriangleMCTSConfig(max_simulations=4), 1, 1, other_dim)
-    H = native.host()
+    H = native.host(env.ROWS * env.COLS)
+    assert eng.wide == (env.ROWS * env.COLS > 256) and eng.state_bytes == H.STATE_BYTES
     before, actions, after, rewards, dones = [], [], [], [], []
     for seed in range(6):
         g = GameState(env, initial_seed=seed)
@@ -81,15 +88,16 @@ class _SyntheticNet:
 
 
 @pytest.mark.parametrize("compact", [False, True])
-@pytest.mark.parametrize("leaves,large", [(1, False), (3, False), (1, True)])
+@pytest.mark.parametrize("leaves,large", [(1, False), (3, False), (1, True), (1, "wide"), (2, "wide")])
 def test_tree_search_equals_host_search(leaves, large, compact):
-    env = EnvConfig.large() if large else EnvConfig()  # the large board (756 actions) takes the strided edge-scan path
+    # the large board (756 actions) takes the strided edge-scan path; "wide" (18x18, 972 actions) the 160-byte-state build
+    env = _WIDE_ENV if large == "wide" else EnvConfig.large() if large else EnvConfig()
     sims = 48
     mcts = AlphaTriangleMCTSConfig(max_simulations=sims, max_depth=6, dirichlet_epsilon=0.0, mcts_batch_size=leaves)
     G = 6
     eng = _engine(env, mcts, G, leaves, compact=compact)  # compact: leaves that need the network get dense rows
     net = _SyntheticNet(env.ROWS * env.COLS, 30, env.ACTION_DIM)
-    H = native.host()
+    H = native.host(env.ROWS * env.COLS)
     games = []
     rng = random.Random(3)
     for i in range(G):
@@ -125,7 +133,7 @@ def test_tree_search_equals_host_search(leaves, large, compact):
         hg, ho = H.extract_features_batch(core_states, 1, 30, env.ROWS, env.COLS)
         return net(hg, ho)
 
-    params = mcts.to_search_params(leaf_batch=leaves)
+    params = mcts.to_search_params(leaf_batch=leaves, module=H)
     # the device runs `waves` full waves; give the host the same simulation budget
     params.max_simulations = waves * leaves
     for i, g in enumerate(games):
@@ -135,14 +143,14 @@ def test_tree_search_equals_host_search(leaves, large, compact):
         assert hv.sum() > 0
 
 
-def _actor(games=48, sims=12, graphs=True, leaves=1, seed=7, dtype="bf16", model=None, hip_engine=None):
+def _actor(games=48, sims=12, graphs=True, leaves=1, seed=7, dtype="bf16", model=None, hip_engine=None, env=None):
     from alphatriangle_amd.models.network import NeuralNetwork
     from alphatriangle_amd.rl.core.device_buffer import DeviceReplayBuffer
     from alphatriangle_amd.rl.self_play.gpu_actor import GpuSelfPlayActor
 
     torch.manual_seed(0)
     dev = torch.device("cuda")
-    env, mc = EnvConfig(), model or ModelConfig()
+    env, mc = env or EnvConfig(), model or ModelConfig()
     tc = TrainConfig(DEVICE="cuda", BUFFER_CAPACITY=20000, MIN_BUFFER_SIZE_TO_TRAIN=64, BATCH_SIZE=32, N_STEP_RETURNS=3, MAX_TRAINING_STEPS=1000)
     sc = SystemConfig(GAMES_PER_GPU=games, LEAVES_PER_TREE=leaves, USE_HIP_GRAPHS=graphs, INFERENCE_DTYPE=dtype)
     mcts = AlphaTriangleMCTSConfig(max_simulations=sims, max_depth=5)
@@ -174,6 +182,29 @@ def test_play_move_invariants_and_replay_flow():
     assert batch is not None and batch.grid.shape == (32, 1, 8, 15) and batch.policy_target.shape == (32, 360)
     assert (batch.indices >= 0).all() and (batch.indices < n).all()
     assert ((batch.weights > 0) & (batch.weights <= 1.0 + 1e-6)).all()
+
+
+def test_gpu_actor_plays_a_board_above_256_cells():
+    """18x18 board: wide device engine (tree, commit, re-root, replay writes), leaves through the PyTorch module because no
+    HIP inference engine tiles that board; replay rows and search policies keep their invariants."""
+    from alphatriangle_amd.rl.self_play.gpu_actor import ModuleEvaluator
+
+    actor, replay, tc = _actor(games=24, sims=10, dtype="fp32", model=ModelConfig.cnn_only(), env=_WIDE_ENV)
+    assert actor.tree.wide and isinstance(actor.evaluator, ModuleEvaluator)
+    total = 0
+    for _ in range(6):
+        rep = actor.play_move()
+        assert rep.moves == actor.G and rep.simulations >= actor.G * 10
+        total += rep.experiences_added
+    n = len(replay)
+    assert n == total and n >= actor.G * 2
+    pol = replay.policy[:n]
+    assert pol.shape[1] == _WIDE_ENV.ACTION_DIM and torch.allclose(pol.sum(1), torch.ones(n, device=pol.device), atol=1e-4)
+    assert torch.isfinite(replay.ret[:n]).all()
+    grid = replay.grid[:n].view(n, 18, 18)
+    assert ((grid == 1) | (grid == 0) | (grid == -1)).all() and (grid[:, :, 0] == -1).all()  # death columns of the board
+    batch = replay.sample(16, current_train_step=0)
+    assert batch is not None and batch.grid.shape == (16, 1, 18, 18)
 
 
 def test_per_game_step_metrics_and_slot_census():
