@@ -104,14 +104,24 @@ class EngineEvaluator(LeafEvaluator):
 
 
 class ModuleEvaluator(LeafEvaluator):
-    """The PyTorch module in eval mode and fp32: any ``ModelConfig`` the reference accepts, same tree kernels.
+    """The PyTorch module in eval mode (fp32, or bf16 autocast when that is the requested precision): any ``ModelConfig``
+    and any board the reference accepts, same tree kernels.
 
     It keeps a private eval-mode copy of the module, because the learner switches the shared one to training mode
-    (BatchNorm batch statistics, dropout) and may update it on another stream while a search is running.
+    (BatchNorm batch statistics, dropout) and may update it on another stream while a search is running.  With batch
+    compaction it evaluates the dense rows only: the row count comes back to the host once per wave (one small
+    synchronous copy - this evaluator is launched eagerly, so it does not break a graph), rounded up to a quarter of the
+    batch, so that the library sees four batch sizes: MIOpen builds its convolution kernels per shape at first use, and
+    with a step of 64 rows a bf16 run spent minutes compiling when its first games ended and the batches thinned out.
     """
 
-    def __init__(self, nn: NeuralNetwork, batch: int, chunk: int = 2048):
+    supports_live = True
+
+    def __init__(self, nn: NeuralNetwork, batch: int, chunk: int = 2048, dtype: str = "fp32"):
         self.nn = nn
+        self.dtype = "bf16" if dtype == "bf16" else "fp32"
+        self.rows_evaluated = 0  # rows sent through the module since construction (tests, logging)
+        self.row_step = max(64, (int(batch) + 255) // 256 * 64)  # a quarter of the batch, in whole 64-row blocks
         dev = nn.device
         mc, ec = nn.model_config, nn.env_config
         self.module = copy.deepcopy(nn._orig_model).to(dev).eval()
@@ -129,8 +139,15 @@ class ModuleEvaluator(LeafEvaluator):
         self.chunk = int(chunk)
 
     @torch.no_grad()
-    def forward(self, grid: torch.Tensor, other: torch.Tensor, live: torch.Tensor | None = None) -> None:  # noqa: ARG002 - all rows
+    def forward(self, grid: torch.Tensor, other: torch.Tensor, live: torch.Tensor | None = None) -> None:
         B = int(grid.shape[0])
+        if live is not None:
+            n = int(live.item())
+            B = min(B, (n + self.row_step - 1) // self.row_step * self.row_step)
+            if B == 0:
+                return
+            grid, other = grid[:B], other[:B]
+        self.rows_evaluated += B
         if self.planes is not None:
             self.planes[:B, 0] = grid.view(B, self.shape[1], self.shape[2])
             x = self.planes[:B]
@@ -138,7 +155,8 @@ class ModuleEvaluator(LeafEvaluator):
             x = grid.view(B, *self.shape)
         for s in range(0, B, self.chunk):
             e = min(B, s + self.chunk)
-            pl, vl = self.module(x[s:e], other[s:e])
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.dtype == "bf16" and x.is_cuda):
+                pl, vl = self.module(x[s:e], other[s:e])
             self.logits[s:e, : self.A].copy_(pl.float())
             torch.sum(torch.softmax(vl.float(), dim=1) * self.support, dim=1, out=self.values[s:e])
 
@@ -158,10 +176,11 @@ def make_evaluator(nn: NeuralNetwork, system_config: SystemConfig, batch: int) -
     if engine is not None and want == "bf16":
         return EngineEvaluator(nn, batch)
     if engine is None:
-        logger.warning("No HIP inference engine for this model configuration: leaves are evaluated by the PyTorch module (fp32).")
+        logger.warning("No HIP inference engine for this model configuration: leaves are evaluated by the PyTorch module (%s).",
+                       "bf16 autocast" if want == "bf16" else "fp32")
     else:
         logger.info("INFERENCE_DTYPE=%s: leaves are evaluated by the PyTorch module in fp32.", want)
-    return ModuleEvaluator(nn, batch)
+    return ModuleEvaluator(nn, batch, dtype=want if engine is None else "fp32")
 
 
 class GpuSelfPlayActor:

@@ -143,7 +143,7 @@ def test_tree_search_equals_host_search(leaves, large, compact):
         assert hv.sum() > 0
 
 
-def _actor(games=48, sims=12, graphs=True, leaves=1, seed=7, dtype="bf16", model=None, hip_engine=None, env=None):
+def _actor(games=48, sims=12, graphs=True, leaves=1, seed=7, dtype="bf16", model=None, hip_engine=None, env=None, compact=True):
     from alphatriangle_amd.models.network import NeuralNetwork
     from alphatriangle_amd.rl.core.device_buffer import DeviceReplayBuffer
     from alphatriangle_amd.rl.self_play.gpu_actor import GpuSelfPlayActor
@@ -152,7 +152,7 @@ def _actor(games=48, sims=12, graphs=True, leaves=1, seed=7, dtype="bf16", model
     dev = torch.device("cuda")
     env, mc = env or EnvConfig(), model or ModelConfig()
     tc = TrainConfig(DEVICE="cuda", BUFFER_CAPACITY=20000, MIN_BUFFER_SIZE_TO_TRAIN=64, BATCH_SIZE=32, N_STEP_RETURNS=3, MAX_TRAINING_STEPS=1000)
-    sc = SystemConfig(GAMES_PER_GPU=games, LEAVES_PER_TREE=leaves, USE_HIP_GRAPHS=graphs, INFERENCE_DTYPE=dtype)
+    sc = SystemConfig(GAMES_PER_GPU=games, LEAVES_PER_TREE=leaves, USE_HIP_GRAPHS=graphs, INFERENCE_DTYPE=dtype, COMPACT_LEAF_BATCH=compact)
     mcts = AlphaTriangleMCTSConfig(max_simulations=sims, max_depth=5)
     net = NeuralNetwork(mc, env, tc, dev, use_hip_engine=hip_engine, inference_dtype=dtype)
     replay = DeviceReplayBuffer(tc, env, mc, dev, sc)
@@ -319,6 +319,33 @@ def test_gpu_tree_with_pytorch_leaf_evaluator_for_untiled_models():
     actor.sync_weights(3)
     src, dst = actor.nn._orig_model.state_dict(), actor.evaluator.module.state_dict()
     assert all(torch.equal(src[k], dst[k]) for k in src)
+
+
+def test_module_evaluator_skips_dead_rows_and_runs_in_bf16():
+    """With batch compaction the PyTorch evaluator sends only the dense rows (rounded up to a quarter of the batch) through the module; the
+    search it feeds picks (nearly always) the same moves as the one that evaluates every row.  With the bf16 engine
+    requested and no HIP engine for the model it runs under bf16 autocast and says so."""
+    mc = ModelConfig(GRID_INPUT_CHANNELS=2, CONV_FILTERS=[16, 24], CONV_KERNEL_SIZES=[5, 3], CONV_STRIDES=[1, 1], CONV_PADDING=[2, 1],
+                     NUM_RESIDUAL_BLOCKS=1, RESIDUAL_BLOCK_FILTERS=24, USE_TRANSFORMER=False, TRANSFORMER_LAYERS=0,
+                     FC_DIMS_SHARED=[48], POLICY_HEAD_DIMS=[48], VALUE_HEAD_DIMS=[48], ACTIVATION_FUNCTION="Tanh")
+    dense, _, _ = _actor(games=200, sims=8, dtype="fp32", model=mc)
+    assert dense.compact and dense.evaluator.supports_live
+    full, _, _ = _actor(games=200, sims=8, dtype="fp32", model=mc, compact=False)
+    assert not full.compact
+    same = 0
+    for _ in range(4):
+        dense.play_move()
+        full.play_move()
+        torch.cuda.synchronize()
+        same += int((dense.tree.chosen_action == full.tree.chosen_action).sum())
+    assert same >= 0.9 * 4 * 200, same  # library kernels may differ by batch size in the last bits; the games stay together
+    # root evaluation (all rows) + 8 waves per move; the dense actor never evaluates more rows than the full one
+    assert full.evaluator.rows_evaluated == 4 * 9 * 200
+    assert dense.evaluator.row_step == 64 and dense.evaluator.rows_evaluated <= full.evaluator.rows_evaluated + 4 * 9 * 64
+    half, _, _ = _actor(games=24, sims=8, dtype="bf16", model=mc)
+    assert half.nn.engine is None and half.dtype == "bf16" and half.evaluator.dtype == "bf16"
+    rep = half.play_move()
+    assert rep.moves == half.G and torch.isfinite(half.evaluator.logits).all()
 
 
 def test_graph_replay_equals_eager():

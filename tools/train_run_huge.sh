@@ -8,6 +8,9 @@ root="$(cd "$(dirname "$0")/.." && pwd)"
 out="$root/gpurun_out/train_huge"
 mkdir -p "$out"
 cd "$root"
+( while true; do sleep 60; echo "[tick] $(date +%T)" >> "$out/ticks.txt"; done ) &
+TICK=$!
+trap "kill $TICK 2>/dev/null || true" EXIT
 timeout -k 10 500 python3 -u -m alphatriangle_amd train --preset huge --max-steps "$steps" --simulations "$sims" "$@" \
   --data-root "$out/data" --run-name huge --log-level INFO > "$out/train.log" 2>&1
 grep -E "host engine|Determined|Initialized|GpuTreeEngine|GpuSelfPlayActor|leaf|Training finished|completed|steps/sec|Final|Error|error" "$out/train.log" | tail -25 > "$out/train_log_excerpt.txt" || true
