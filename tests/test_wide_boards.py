@@ -129,3 +129,21 @@ def test_cpu_training_run_on_a_board_above_256_cells(tmp_path):
                         env_config_override=env, system_config_override=SystemConfig(ENGINE="auto")) == 0
     ck = Serializer().load_checkpoint(tmp_path / "WIDE" / "runs" / "wide" / "checkpoints" / "latest.pkl")
     assert ck.global_step == 6 and ck.episodes_played > 0
+
+
+def test_huge_preset_is_a_600_cell_board_with_a_network_sized_for_it():
+    """The named preset for boards above 256 cells: geometry, action space, network shapes, host search on it."""
+    import torch
+
+    from alphatriangle_amd.models.network import NeuralNetwork
+    from alphatriangle_amd.presets import build_preset
+
+    env, model, mcts, train, system = build_preset("huge")
+    assert (env.ROWS, env.COLS, env.ACTION_DIM) == (20, 30, 1800) and system.ENGINE == "auto" and system.GAMES_PER_GPU == 1024
+    g = GameState(env, 5)
+    assert native.host_of(g.geometry) is native.host(600) and g.geometry.playable_count < 600  # the corners are cut off
+    net = NeuralNetwork(model, env, train.model_copy(update={"DEVICE": "cpu"}), torch.device("cpu"))
+    policy, value = net.evaluate_state(g)
+    assert len(policy) == 1800 and abs(sum(policy.values()) - 1.0) < 1e-4 and np.isfinite(value)
+    visits, _ = run_mcts(g, net, mcts.model_copy(update={"max_simulations": 12, "mcts_batch_size": 4}), seed=2)
+    assert sum(visits.values()) == 12 and all(g.valid_mask()[a] for a in visits)
