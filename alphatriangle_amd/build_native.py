@@ -3,7 +3,8 @@
 * ``_atri_host``  - host C++ runtime (pybind11, g++): game engine, features,
   host tree search, sum tree, metric ring.
 * ``_atri_host_wide`` - the same sources compiled with 16 occupancy words per
-  game state: boards of 257 - 1024 cells (host engine only).
+  game state: boards of 257 - 1024 cells (the kernel library holds the
+  device engine for them as a second object of ``engine_kernels.hip``).
 * ``libatri_hip`` - HIP/CDNA4 kernels for gfx950 (hipcc): batched game + tree
   engine, inference network, replay and learner kernels.  Exposed with a C ABI
   and loaded through ctypes after ``import torch`` so that it binds to the same

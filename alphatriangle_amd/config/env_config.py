@@ -41,8 +41,8 @@ class EnvConfig(BaseModel):
     @model_validator(mode="after")
     def _check_geometry(self) -> "EnvConfig":
         if self.ROWS * self.COLS > 1024:
-            # up to 256 cells: the 64-byte state of the host and the device engine; up to 1024: the wide host build
-            raise ValueError("ROWS * COLS must be <= 1024 (bitboard of sixteen 64-bit words in the wide host engine).")
+            # up to 256 cells: the 64-byte state of the host and the device engine; up to 1024: their wide builds (160 bytes)
+            raise ValueError("ROWS * COLS must be <= 1024 (bitboard of sixteen 64-bit words in the wide engine builds).")
         if len(self.PLAYABLE_RANGE_PER_ROW) != self.ROWS:
             raise ValueError(
                 f"PLAYABLE_RANGE_PER_ROW needs {self.ROWS} entries, got {len(self.PLAYABLE_RANGE_PER_ROW)}."

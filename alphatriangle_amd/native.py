@@ -24,7 +24,7 @@ _host_mods: dict[str, ModuleType] = {}
 _hip_lib: ctypes.CDLL | None = None
 
 NARROW_CELLS = 256   # four 64-bit occupancy words: the 64-byte state shared with the device engine
-WIDE_CELLS = 1024    # sixteen words: the wide host module (host engine only)
+WIDE_CELLS = 1024    # sixteen words: the wide host module (and the atriw_* entry points of the kernel library)
 
 
 class NativeLibraryError(RuntimeError):
