@@ -1,6 +1,6 @@
 #!/bin/bash
 # A second build of the kernel library with one source compiled differently, for same-box A/B runs (ATRI_HIP_LIB=<out>):
-#   tools/build_variant.sh <out.so> <source.hip> [extra hipcc flags, e.g. -DATRI_ENC_STAGGER=12]
+#   tools/build_variant.sh <out.so> <source.hip> [extra hipcc flags, e.g. -DATRI_SPLIT_NOMIX=1]
 # Every other object comes from the regular in-tree build (alphatriangle_amd/build/hip), which has to be up to date.
 set -eo pipefail
 out="$1"; src="$2"; shift 2
